@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE.  Generates tests/golden/ by running the *compiled reference*
+(oracle/_ref/pw_ref, built by `make -C oracle ref` from /root/reference in place) on seeded
+inputs.  Only data is committed: the input MSA, the bytes of the reference's output file (or the
+fact that it wrote none), its exit code and its stdout score lines.  Runs only where the
+reference exists (the build container); the GPU box sees just the fixtures.
+
+    python oracle/gen_golden.py            # regenerate everything
+"""
+import gzip
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from repeatresolver_amd import datagen as dg  # noqa: E402
+
+REF = os.path.join(HERE, "_ref", "pw_ref")
+IA = os.path.join(HERE, "_ref", "initial_aligner")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def msa_bytes(m: np.ndarray) -> bytes:
+    out = np.empty((m.shape[0], m.shape[1] + 1), dtype=np.uint8)
+    out[:, :-1] = m
+    out[:, -1] = 10
+    return out.tobytes()
+
+
+def from_rows(rows) -> bytes:
+    w = len(rows[0])
+    assert all(len(r) == w for r in rows)
+    return ("\n".join(rows) + "\n").encode()
+
+
+def sim(**kw) -> bytes:
+    return msa_bytes(dg.build_msa(dg.simulate(dg.SimConfig(**kw))))
+
+
+def via_initial_aligner(**kw) -> bytes:
+    """Reads from our generator, MSA from the reference's own upstream tool (InitialAligner.c)."""
+    d = dg.simulate(dg.SimConfig(**kw))
+    with tempfile.TemporaryDirectory() as td:
+        dg.write_fasta(os.path.join(td, "x_Template.fasta"), [d.template])
+        dg.write_fasta(os.path.join(td, "x_Seq.fasta"), d.reads)
+        subprocess.run([IA, "x_Template.fasta", "x_Seq.fasta", "-o", "x_MSA", "-p", "4"], cwd=td,
+                       check=True, stdout=subprocess.DEVNULL)
+        with open(os.path.join(td, "x_MSA"), "rb") as f:
+            return f.read()
+
+
+def write_gz(path, data: bytes):
+    with open(path, "wb") as raw, gzip.GzipFile(filename="", mode="wb", compresslevel=9, fileobj=raw, mtime=0) as f:
+        f.write(data)
+
+
+def run_ref(inp: bytes, args):
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "in.msa"), "wb") as f:
+            f.write(inp)
+        p = subprocess.run([REF, "in.msa", "-o", "out.msa"] + args, cwd=td, capture_output=True, timeout=3600)
+        outp = os.path.join(td, "out.msa")
+        out = open(outp, "rb").read() if os.path.exists(outp) else None
+        lines = [l for l in p.stdout.decode("latin1").splitlines()
+                 if l.startswith("OverallScore") or l.startswith("Rows ") or l.startswith("bandwidth")]
+        return p.returncode, out, lines
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    cases = []
+
+    def add(name, inp, args, note):
+        rc, out, lines = run_ref(inp, args)
+        write_gz(os.path.join(OUT, name + ".in.gz"), inp)
+        if out is not None:
+            write_gz(os.path.join(OUT, name + ".out.gz"), out)
+        bw = 1000
+        if "-b" in args:
+            bw = int(args[args.index("-b") + 1])
+        cases.append({"name": name, "bandwidth": bw, "exit_code": rc, "wrote_output": out is not None,
+                      "stdout": lines, "note": note})
+        print(name, "rc", rc, "out", None if out is None else len(out), lines[-1] if lines else "")
+        return out
+
+    toy_a = sim(kind="Tree", copies=4, coverage=8, difference=0.01, repeat_len=1500, flank=500,
+                length_scale=0.08, min_aligned=100, seed=11)
+    out_a = add("toy_a_b1000", toy_a, [], "68 rows, truth-aligned MSA, default bandwidth")
+    add("toy_a_b50", toy_a, ["-b", "50"], "narrow band: right-edge extension and big-gap jumps")
+    add("toy_a_b7", toy_a, ["-b", "7"], "odd bandwidth, half = 3")
+    add("toy_a_resume", out_a, [], "re-run on the reference's own output: upper case + blanks, writes no file")
+    ia = via_initial_aligner(kind="Tree", copies=4, coverage=8, difference=0.01, repeat_len=1500, flank=500,
+                             length_scale=0.08, min_aligned=100, seed=21)
+    add("ia_toy_b1000", ia, [], "MSA produced by the reference's InitialAligner from our seeded reads")
+    add("ia_toy_b120", ia, ["-b", "120"], "same, bandwidth 120")
+    tiny = sim(kind="Tree", copies=2, coverage=5, difference=0.02, repeat_len=300, flank=100,
+               length_scale=0.02, min_aligned=30, seed=5)
+    add("tiny_b1000", tiny, [], "tiny: band always clamped at both MSA edges")
+    add("tiny_b10", tiny, ["-b", "10"], "tiny, bandwidth 10")
+    add("tiny_b2", tiny, ["-b", "2"], "tiny, bandwidth 2")
+    deep = sim(kind="Tree", copies=12, coverage=14, difference=0.01, repeat_len=600, flank=200,
+               length_scale=0.04, min_aligned=60, seed=7)
+    add("deep_b200", deep, ["-b", "200"], "deeper stack (coverage ~170), bandwidth 200")
+    lowcov = sim(kind="Distributed", copies=2, coverage=2, difference=0.02, repeat_len=1200, flank=400,
+                 length_scale=0.05, min_aligned=50, seed=9)
+    add("lowcov_b300", lowcov, ["-b", "300"], "low coverage: rows slide apart, many column insertions")
+    # hand-made edge cases
+    add("edge_single_row", from_rows(["--acgtacgt--"]), [], "single row: first round cannot improve, no file")
+    add("edge_identical", from_rows(["acgtacgtac"] * 4), [], "identical rows, score 0, no file")
+    add("edge_empty_row", from_rows(["acgt-acgtacg", "------------", "ac-tgacgtacg", "acgtgacg-a-g", "-cgtgacgta--"]),
+        ["-b", "6"], "a row without bases")
+    add("edge_mixed_case", from_rows(["ACgt_acgTAcg", "  gtaacg-acg", "ac-tgAcgta  ", "acgtgacg-a-g", " cgtgacgta- "]),
+        ["-b", "8"], "upper case, '_' as gap, blank margins")
+    add("edge_shift", from_rows(["acgtacgtacgtacgt--------", "----acgtacgtacgtacgt----", "--------acgtacgtacgtacgt",
+                                 "acgtacgtacgtacgt--------", "--acgtacgtacgtacgtac----"]),
+        ["-b", "12"], "rows offset against each other: insertions at both MSA ends")
+    toy_b = sim(kind="Tree", copies=10, coverage=12, difference=0.01, repeat_len=4000, flank=1500,
+                length_scale=0.25, min_aligned=200, seed=12)
+    add("toy_b_b1000", toy_b, [], "248 rows x 11780 columns, ~17 s of CPU")
+    with open(os.path.join(OUT, "cases.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py", "reference_build": "gcc -O2 -mcmodel=medium PW_ReAligner.c",
+                   "cases": cases}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
