@@ -1,0 +1,100 @@
+/*
+ * pwr.h -- C ABI of the MI355X-native PW_ReAligner hot path (libpwr.so).
+ *
+ * The reference (PhilippBongartz/RepeatResolver, PW_ReAligner.c, cited as "PW:") has no library
+ * interface: its boundary is the process (`./PW_ReAligner <MSA> [-o out] [-b bw]`) and, inside it,
+ * a handful of functions working on file-scope globals.  Each entry point below replaces one of
+ * those functions; the context object replaces the globals (PW:30-52, PW:86-90).  Plain C types
+ * only, `int` status returns (0 = ok, negative = error), no callbacks, a context is not
+ * thread-safe.  The MSA state lives in HBM for the lifetime of the context.
+ *
+ * Symbols: the text alphabet is `acgtACGT-_` and ' ' on input (PW:165-222) and `ACGT- ` on
+ * output (PW:1558-1563).
+ */
+#ifndef PWR_H
+#define PWR_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWR_OK 0
+#define PWR_ERR_ARG (-1)         /* bad argument */
+#define PWR_ERR_NOMEM (-2)       /* host or device allocation failed (PW:55-75) */
+#define PWR_ERR_DEVICE (-3)      /* HIP runtime error / no usable GPU */
+#define PWR_ERR_INPUT (-4)       /* malformed MSA text (PW:121, PW:134; unequal line lengths) */
+#define PWR_ERR_RANGE (-5)       /* a limit was exceeded (row longer than 35000 bases PW:16,
+                                    bandwidth > 2000 PW:14, scores beyond the 32-bit DP range) */
+#define PWR_ERR_INTERNAL (-6)    /* inconsistent traceback ("Stuff gone wrong", PW:1412-1427) */
+#define PWR_ERR_UNSUPPORTED (-7) /* state the device layout cannot hold (see pwr_create) */
+#define PWR_ERR_IO (-8)          /* output file cannot be opened ("DateiVerbratei!", PW:1568-1572) */
+
+#define PWR_MAX_BANDWIDTH 2000   /* PW:14 */
+#define PWR_MAX_SEQ_LENGTH 35000 /* PW:16 */
+#define PWR_MAX_LINE 699997      /* PW:15, PW:119: fgets buffer of Max_MA_Breadth-2 */
+
+typedef struct pwr_ctx pwr_ctx;
+
+typedef struct pwr_stats {
+    uint64_t cells_reference;   /* DP cells the reference would have filled for the committed
+                                   realignments (one execution of PW:1503-1510 each) */
+    uint64_t cells_computed;    /* DP cells the fill kernel actually computed (includes speculative
+                                   fills that had to be repeated) */
+    uint64_t fill_launches;     /* launches of the DP fill kernel */
+    double fill_ms;             /* sum of HIP-event durations of those launches (profiling on) */
+    uint64_t rows_committed;    /* realignments committed (== Matrix_Filler calls with length>0) */
+    uint64_t rows_recomputed;   /* speculative results discarded because their inputs changed */
+    uint64_t batches;           /* speculative batches launched */
+} pwr_stats;
+
+/* Replaces MMA_Einlesen (PW:93-241) for an in-memory matrix: `text` holds rows*width characters,
+ * row-major, without newlines.  device = HIP device ordinal.  The rows are parsed and kept on the
+ * host until the first device operation.  Realignment needs every row to be of the form
+ * blank* (base|'-')* blank* with a base at both ends of the middle part, which is what
+ * pwr_trim_ends() establishes for any input without blanks between bases and what every
+ * reference-written MSAreal satisfies; other states make the device calls return
+ * PWR_ERR_UNSUPPORTED. */
+int pwr_create(pwr_ctx **out, int rows, int width, const unsigned char *text, int bandwidth, int device);
+void pwr_destroy(pwr_ctx *ctx);
+
+/* EntAlGapper (PW:459-645). */
+int pwr_trim_ends(pwr_ctx *ctx);
+/* Matrix_Filler(k) (PW:1469-1531) including W_Con (PW:706-763) before it. */
+int pwr_realign_row(pwr_ctx *ctx, int k);
+/* The k-loop of one round (PW:1695-1737): every row, in input order.  Results are those of
+ * calling pwr_realign_row for k = 0..rows-1; internally upcoming rows are filled speculatively and
+ * committed in order. */
+int pwr_realign_round(pwr_ctx *ctx);
+/* The integer total that OverallScorePrint prints (PW:864-892, PW:933-963); compacts first. */
+int pwr_total_score(pwr_ctx *ctx, uint64_t *total);
+/* Tiefe / current Breite (PW:86-87). */
+int pwr_dims(pwr_ctx *ctx, int *rows, int *width);
+/* MMA_Auslesen (PW:1556-1598) into memory: rows*width characters, row-major, no newlines. */
+int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
+
+/* Knobs and counters (ours). keys: "window" (max rows filled speculatively per batch, >= 1),
+ * "profile" (1 = time every fill launch with HIP events), "threads" (512 or 1024 per DP). */
+int pwr_set_option(pwr_ctx *ctx, const char *key, long value);
+int pwr_get_stats(pwr_ctx *ctx, pwr_stats *out);
+int pwr_reset_stats(pwr_ctx *ctx);
+const char *pwr_strerror(int code);
+/* Number of HIP devices visible, or a negative error. */
+int pwr_device_count(void);
+
+/* ---- host side of the boundary, plain C (pwr_host.c) ---- */
+/* Reads the MSA text file exactly as PW:118-136 does, but refuses unequal line lengths. On
+ * success *text is malloc'ed (rows*width bytes). */
+int pwr_read_msa_file(const char *path, int *rows, int *width, unsigned char **text, char *err, size_t errcap);
+int pwr_write_msa_file(const char *path, int rows, int width, const unsigned char *text);
+/* main() of the reference (PW:1610-1759) on top of the calls above: same stdout lines, same
+ * output-file behaviour, returns the process exit code. max_rounds < 0: until convergence. */
+int pwr_run_file(const char *in_path, const char *out_path, int bandwidth, int device, int max_rounds, FILE *log);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PWR_H */

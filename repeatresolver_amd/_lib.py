@@ -1,0 +1,63 @@
+"""ctypes loader for csrc/libpwr.so (the C ABI of include/pwr.h).  There is no fallback: if the
+HIP library is missing the import of the product path fails loudly."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpwr.so")
+
+
+class PwrStats(ctypes.Structure):
+    _fields_ = [("cells_reference", ctypes.c_uint64), ("cells_computed", ctypes.c_uint64),
+                ("fill_launches", ctypes.c_uint64), ("fill_ms", ctypes.c_double),
+                ("rows_committed", ctypes.c_uint64), ("rows_recomputed", ctypes.c_uint64),
+                ("batches", ctypes.c_uint64)]
+
+
+# every symbol include/pwr.h declares
+EXPORTS = ["pwr_create", "pwr_destroy", "pwr_trim_ends", "pwr_realign_row", "pwr_realign_round",
+           "pwr_total_score", "pwr_dims", "pwr_export_rows", "pwr_set_option", "pwr_get_stats",
+           "pwr_reset_stats", "pwr_strerror", "pwr_device_count", "pwr_read_msa_file",
+           "pwr_write_msa_file", "pwr_run_file"]
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C repeatresolver_amd/csrc`.  There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.pwr_create.restype = ci
+    lib.pwr_create.argtypes = [ctypes.POINTER(vp), ci, ci, ctypes.c_char_p, ci, ci]
+    lib.pwr_destroy.restype = None
+    lib.pwr_destroy.argtypes = [vp]
+    for n in ("pwr_trim_ends", "pwr_realign_round", "pwr_reset_stats"):
+        getattr(lib, n).restype = ci
+        getattr(lib, n).argtypes = [vp]
+    lib.pwr_realign_row.restype = ci
+    lib.pwr_realign_row.argtypes = [vp, ci]
+    lib.pwr_total_score.restype = ci
+    lib.pwr_total_score.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
+    lib.pwr_dims.restype = ci
+    lib.pwr_dims.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    lib.pwr_export_rows.restype = ci
+    lib.pwr_export_rows.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
+    lib.pwr_set_option.restype = ci
+    lib.pwr_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_long]
+    lib.pwr_get_stats.restype = ci
+    lib.pwr_get_stats.argtypes = [vp, ctypes.POINTER(PwrStats)]
+    lib.pwr_strerror.restype = ctypes.c_char_p
+    lib.pwr_strerror.argtypes = [ci]
+    lib.pwr_device_count.restype = ci
+    lib.pwr_device_count.argtypes = []
+    lib.pwr_debug_last_job.restype = ci
+    lib.pwr_debug_last_job.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci),
+                                       ctypes.POINTER(ci), ctypes.POINTER(ci), ci]
+    _lib = lib
+    return lib

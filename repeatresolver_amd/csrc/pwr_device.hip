@@ -1,0 +1,1308 @@
+// pwr_device.hip -- MI355X (gfx950) implementation of the PW_ReAligner hot path behind include/pwr.h.
+//
+// Reference: PhilippBongartz/RepeatResolver, PW_ReAligner.c ("PW:").  Nothing here is translated
+// from it; the reference is a single-threaded walk over a linked list of columns with a 64-bit
+// L x 2000 score matrix.  This file keeps the MSA resident in HBM as
+//   * per row:    its base sequence (static) and, per base, the id ("slot") of the column holding it,
+//   * per column: the six tallies w_con[0..5] of PW:41-47 plus the number of rows that END in it,
+//   * the column order (ordinal -> slot) and its inverse (slot -> ordinal),
+// and realigns a row with four kernels: gather (TheWay + Downdater, PW:647-705/1172-1220, into
+// job-private DP inputs), fill (PW:1493-1513), trace (PW:1334-1454) and commit (Column_Updater /
+// Column_Adder / W_Con, PW:1222-1332, PW:706-763).  See DESIGN.md for the derivations.
+//
+// Symbols 0..3 = A,C,G,T, 4 = '-', 5 = ' '.  w[b] = #rows non-blank and != b in the column.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "pwr.h"
+
+#define PWR_INF 0x40000000u        // any value >= this is "unreachable"; finite scores stay below (range check)
+#define PWR_BIG 0x7fffffff
+
+// ---------------------------------------------------------------------------------------------
+// device-side data
+// ---------------------------------------------------------------------------------------------
+struct Hdr {                       // lives in device memory, one per context
+    int W;                         // current width (Breite, PW:87)
+    int nslots;                    // column slots ever handed out
+    int nfree;                     // entries on the free list (the Reservoir of PW:51)
+    int cur;                       // which of the two order buffers is current
+    int status;                    // sticky error (PWR_ERR_*), 0 = fine
+    int stop;                      // batch mode: set when a speculative job failed validation
+    int ncommitted;                // batch mode: jobs committed in the current batch
+    int pad0;
+    unsigned long long cells_computed;
+    unsigned long long cells_reference;
+};
+
+struct Tally {                     // 32 B per column slot
+    uint32_t w[6];                 // PW:46 w_con
+    uint32_t endcnt;               // rows whose last base sits in this column
+    uint32_t pad;
+};
+
+struct JobMeta {                   // 64 B
+    int k, L, lo, hi, W, entry, ok, nnew;
+    unsigned maxS;
+    int valid;                     // batch mode: result still matches the committed state
+    unsigned long long cells;
+    int pad[4];
+};
+
+struct DState {
+    Hdr *hdr;
+    int T, B, H, Lmax;
+    int colcap, slotcap;
+    const long long *rowoff;
+    const int *rowlen;
+    const uint8_t *seq;
+    int *pos;
+    Tally *tally;
+    int *order0, *order1;
+    int *rank;
+    int *freelist;
+    int *inscnt;                   // scratch [colcap], kept all-zero between commits
+    int *newidx;                   // scratch [colcap]
+};
+
+struct JobBufs {
+    JobMeta *meta;
+    int *way;                      // [njobs][Lmax]   ordinal of every base (PW:31 Way)
+    uint4 *rec;                    // [njobs][colcap] DP input records of the job's column interval
+    uint8_t *mark;                 // [njobs][colcap] old symbol marks (base+1 / 0)
+    uint8_t *mark2;                // [njobs][colcap] new symbol marks
+    uint32_t *dirs;                // [njobs][dirstride] traceback record, 2 bits per DP cell
+    int *newcol;                   // [njobs][Lmax]   (ordinal << 1) | opened-a-new-column
+    int *aux;                      // [njobs][Lmax]   slot of every base after the commit
+    int Lmax, colcap, NC;
+    size_t dirstride;
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave / block primitives (gfx950: 64-wide waves, DPP row shifts and row broadcasts)
+// ---------------------------------------------------------------------------------------------
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+#define DPP_WAVE_SHR1 0x138
+
+__device__ __forceinline__ int wave_incl_min(int v)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp(PWR_BIG, v, DPP_ROW_SHR(1), 0xF, 0xF, false); v = min(v, t);
+    t = __builtin_amdgcn_update_dpp(PWR_BIG, v, DPP_ROW_SHR(2), 0xF, 0xF, false); v = min(v, t);
+    t = __builtin_amdgcn_update_dpp(PWR_BIG, v, DPP_ROW_SHR(4), 0xF, 0xF, false); v = min(v, t);
+    t = __builtin_amdgcn_update_dpp(PWR_BIG, v, DPP_ROW_SHR(8), 0xF, 0xF, false); v = min(v, t);
+    t = __builtin_amdgcn_update_dpp(PWR_BIG, v, DPP_ROW_BCAST15, 0xA, 0xF, false); v = min(v, t);
+    t = __builtin_amdgcn_update_dpp(PWR_BIG, v, DPP_ROW_BCAST31, 0xC, 0xF, false); v = min(v, t);
+    return v;
+}
+// prefix-min over lanes 0..15 only (wave totals of at most 16 waves)
+__device__ __forceinline__ int row_incl_min(int v)
+{
+    int t;
+    t = __builtin_amdgcn_update_dpp(PWR_BIG, v, DPP_ROW_SHR(1), 0xF, 0xF, false); v = min(v, t);
+    t = __builtin_amdgcn_update_dpp(PWR_BIG, v, DPP_ROW_SHR(2), 0xF, 0xF, false); v = min(v, t);
+    t = __builtin_amdgcn_update_dpp(PWR_BIG, v, DPP_ROW_SHR(4), 0xF, 0xF, false); v = min(v, t);
+    t = __builtin_amdgcn_update_dpp(PWR_BIG, v, DPP_ROW_SHR(8), 0xF, 0xF, false); v = min(v, t);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_incl_add(unsigned v)
+{
+    unsigned t;
+    t = __builtin_amdgcn_update_dpp(0u, v, DPP_ROW_SHR(1), 0xF, 0xF, false); v += t;
+    t = __builtin_amdgcn_update_dpp(0u, v, DPP_ROW_SHR(2), 0xF, 0xF, false); v += t;
+    t = __builtin_amdgcn_update_dpp(0u, v, DPP_ROW_SHR(4), 0xF, 0xF, false); v += t;
+    t = __builtin_amdgcn_update_dpp(0u, v, DPP_ROW_SHR(8), 0xF, 0xF, false); v += t;
+    t = __builtin_amdgcn_update_dpp(0u, v, DPP_ROW_BCAST15, 0xA, 0xF, false); v += t;
+    t = __builtin_amdgcn_update_dpp(0u, v, DPP_ROW_BCAST31, 0xC, 0xF, false); v += t;
+    return v;
+}
+
+// inclusive block prefix sum; sh needs NT/64 words; ends with a barrier so sh can be reused
+template <int NT>
+__device__ __forceinline__ unsigned block_incl_add(unsigned v, unsigned *sh, unsigned &total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned incl = wave_incl_add(v);
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    unsigned wp = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        unsigned s = sh[w];
+        wp += (w < wave) ? s : 0u;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return incl + wp;
+}
+
+template <int NT>
+__device__ __forceinline__ unsigned block_min_u32(unsigned v, unsigned *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    unsigned r = 0xffffffffu;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) r = min(r, sh[w]);
+    __syncthreads();
+    return r;
+}
+template <int NT>
+__device__ __forceinline__ int block_max_i32(int v, int *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int r = INT_MIN;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) r = max(r, sh[w]);
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ const int *cur_order(const DState &st)
+{
+    return st.hdr->cur ? st.order1 : st.order0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// gather: TheWay (PW:647-705) + Columns_Downdater (PW:1172-1201) into job-private DP inputs.
+// One work-group per job.  The global state is NOT modified: the row's own symbols are
+// subtracted from a private copy of the tallies, so many rows can be gathered from one state.
+//
+// Record of column y (16 B): x = S(y,0) | S(y,1)<<16, y = S(y,2) | S(y,3)<<16  (PW:243 Score),
+//   z = G(y) = sum_{j=lo..y} S(j,4)   (mod 2^32; only differences inside one DP row are used),
+//   w = max(S(y,5), S(y-1,5))  (PW:1507), or PWR_INF where PW:1505 forbids opening a column.
+// ---------------------------------------------------------------------------------------------
+#define GATHER_NT 1024
+__global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, const int *jobrows)
+{
+    __shared__ unsigned sh[GATHER_NT / 64];
+    __shared__ unsigned s_cov[GATHER_NT + 1];
+    const int job = blockIdx.x, tid = threadIdx.x;
+    const int k = jobrows[job];
+    JobMeta *m = &jb.meta[job];
+    const int L = st.rowlen[k];
+    const int W = st.hdr->W;
+    if (L == 0) {
+        if (tid == 0) { m->k = k; m->L = 0; m->ok = 1; m->W = W; m->nnew = 0; m->cells = 0; m->valid = 1; }
+        return;
+    }
+    const long long off = st.rowoff[k];
+    const int *order = cur_order(st);
+    int *way = jb.way + (size_t)job * jb.Lmax;
+    for (int x = tid; x < L; x += GATHER_NT) way[x] = st.rank[st.pos[off + x]];
+    __syncthreads();
+    const int B = st.B, H = st.H;
+    const int way0 = way[0], wayL = way[L - 1];
+    const int a0 = max(0, way0 - H), aL = max(0, wayL - H);
+    const int lo = max(0, a0 - 1), hi = min(W - 1, aL + B - 1);
+    const int n = hi - lo + 1;
+    uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
+    uint4 *rec = jb.rec + (size_t)job * jb.colcap;
+    for (int i = tid; i < n; i += GATHER_NT) mark[i] = 0;
+    __syncthreads();
+    for (int x = tid; x < L; x += GATHER_NT) mark[way[x] - lo] = (uint8_t)(st.seq[off + x] + 1);
+    __syncthreads();
+    unsigned carry = 0, maxS = 0;
+    if (tid == 0) s_cov[0] = 0;
+    for (int base = 0; base < n; base += GATHER_NT) {
+        const int i = base + tid;
+        const bool valid = i < n;
+        const int y = lo + i;
+        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+        if (valid) {
+            const Tally t = st.tally[order[y]];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) w[b] = t.w[b];
+            if (y >= way0 && y <= wayL) {          // the row's own symbol: a base or '-'
+                const int mk = mark[i];
+                const int own = mk ? mk - 1 : 4;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) w[b] -= (b != own) ? 1u : 0u;
+            }
+        }
+        unsigned tot;
+        const unsigned gin = block_incl_add<GATHER_NT>(w[4], sh, tot);   // barriers inside
+        s_cov[tid + 1] = w[5];
+        __syncthreads();
+        const unsigned covl = s_cov[tid];
+        __syncthreads();
+        if (tid == GATHER_NT - 1) s_cov[0] = w[5];
+        if (valid) {
+            const unsigned upc = (y == 0 || y == W - 1) ? PWR_INF : max(w[5], covl);
+            rec[i] = make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), carry + gin, upc);
+            maxS = max(maxS, max(max(w[0], w[1]), max(max(w[2], w[3]), max(w[4], w[5]))));
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    // 32-bit DP range: every finite score is at most (L + columns) * maxS (one step per base or
+    // column, each costing at most maxS); unreachable cells are >= PWR_INF; prefix-sum offsets
+    // inside one DP row add at most (B + lookahead) * maxS.
+    const unsigned mx = (unsigned)(~block_min_u32<GATHER_NT>(~maxS, sh));
+    if (tid == 0) {
+        const unsigned long long bound = (unsigned long long)mx * (unsigned long long)(L + n + 2 * B + 4096);
+        m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx;
+        m->cells = 0; m->valid = 1;
+        m->ok = (mx <= 0xffffu && bound < (unsigned long long)PWR_INF) ? 1 : 0;
+        if (!m->ok) atomicCAS(&st.hdr->status, 0, PWR_ERR_RANGE);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fill: the banded DP of PW:1493-1513 for one row per work-group.
+//
+// Thread t owns band cells j = t*C .. t*C+C-1 of every DP row x (column y = anf(x) + j).
+// The dependency on the left neighbour, M(x,y) = min(t(y), M(x,y-1) + S(y,4)), is a min-plus
+// scan:  M(x,y) = G(y) + min_{j<=y} (t(j) - G(j))  with  t = min(diag, up)  and G the prefix sum of
+// S(.,4); it is evaluated with one DPP wave scan per row plus one LDS exchange between waves.
+// The same formula yields the virtual right extension of PW:285-295 for columns past the band.
+// Previous-row values travel through an LDS ring indexed by absolute column; the column records
+// are staged in a second LDS ring, NC columns at a time.
+// Output: 2 bits per cell -- A: "M == M(x,y-1)+S(y,4)" (PW:1375; on the last row also PW:1386),
+// C: "diag <= up" -- which is all the traceback's ordered equality tests need, and the entry
+// column of PW:1352-1360.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int C>
+__global__ __launch_bounds__(NT) void k_fill(DState st, JobBufs jb)
+{
+    constexpr int NC = NT * C, RC = 4 * NC, RCM = RC - 1, MC = 2 * NC, MCM = MC - 1, NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4 *ring = reinterpret_cast<uint4 *>(smem);
+    unsigned *mring = reinterpret_cast<unsigned *>(smem + (size_t)RC * 16);
+    int *wtot = reinterpret_cast<int *>(mring + MC);
+    unsigned *red = reinterpret_cast<unsigned *>(wtot + 16);
+
+    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    JobMeta *m = &jb.meta[job];
+    const int L = m->L;
+    if (L <= 0 || !m->ok) return;
+    const int lo = m->lo, hi = m->hi, W = m->W, B = st.B, H = st.H;
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const uint8_t *seq = st.seq + st.rowoff[m->k];
+    const uint4 *rec = jb.rec + (size_t)job * jb.colcap;
+    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+
+    int loaded_hi = lo;
+    unsigned accA[C], accC[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) accA[i] = accC[i] = 0;
+    unsigned long long cells = 0;
+    int a = max(0, way[0] - H);
+
+    for (int x = 0; x < L; ++x) {
+        const int a_next = (x + 1 < L) ? max(0, way[x + 1] - H) : a;
+        const int Bx = min(B, W - a);
+        const int sx = seq[x];
+        // ---- stage column records: keep [a-1, a+B+NC) resident
+        {
+            const int need_hi = min(hi + 1, a + B + NC);
+            if (loaded_hi < need_hi) {
+                if (loaded_hi < a - 1) loaded_hi = max(lo, a - 1);
+                while (loaded_hi < need_hi) {
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        const int y = loaded_hi + i * NT + tid;
+                        if (y <= hi) ring[y & RCM] = rec[y - lo];
+                    }
+                    loaded_hi += NC;
+                }
+                __syncthreads();
+            }
+        }
+        const unsigned Gb = ring[a & RCM].z;
+        // ---- candidates from the previous DP row
+        int tg[C], grel[C];
+        bool fc[C];
+        int run = PWR_BIG;
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int j = tid * C + i;
+            const int y = a + j;
+            const uint4 r = ring[y & RCM];
+            grel[i] = (int)(r.z - Gb);
+            unsigned pm = 0, pm1 = 0;                       // x == 0: MatrixOut(-1, .) = 0 (PW:256)
+            if (x > 0) { pm = mring[y & MCM]; pm1 = mring[(y - 1) & MCM]; }
+            const unsigned sy = (((sx & 2) ? r.y : r.x) >> ((sx & 1) * 16)) & 0xffffu;
+            const unsigned diag = pm1 + sy;                 // PW:1503
+            const unsigned up = pm + r.w;                   // PW:1507 (r.w = INF where PW:1505 forbids)
+            const unsigned t = min(min(diag, up), PWR_INF);
+            fc[i] = diag <= up;
+            tg[i] = (j < Bx) ? (int)t - grel[i] : PWR_BIG;
+            run = min(run, tg[i]);
+        }
+        // ---- min-plus scan across the band
+        const int incl = wave_incl_min(run);
+        const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();                                    // B1: also orders all mring reads before the writes below
+        int wv = (lane < NW) ? wtot[lane] : PWR_BIG;
+        wv = row_incl_min(wv);
+        const int ptot = __builtin_amdgcn_readlane(wv, NW - 1);
+        const int xw = (wave == 0) ? PWR_BIG : __builtin_amdgcn_readlane(wv, wave > 0 ? wave - 1 : 0);
+        int p = min(xw, excl);
+        // ---- finish cells, record traceback bits, publish the row for x+1
+        int Mv[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int j = tid * C + i;
+            const int y = a + j;
+            bool fa = tg[i] >= p;                           // prefix minimum did not drop: M == left + S(y,4)
+            const int pex = p;
+            p = min(p, tg[i]);
+            const int M = grel[i] + p;
+            Mv[i] = M;
+            if (x == L - 1 && j > 0) {                      // PW:1386: on the last row "M == left" also moves left
+                const int gl = (int)(ring[(y - 1) & RCM].z - Gb);
+                fa = fa || (M == gl + pex);
+            }
+            accA[i] = (accA[i] << 1) | (fa ? 1u : 0u);
+            accC[i] = (accC[i] << 1) | (fc[i] ? 1u : 0u);
+            if (j < Bx && y >= a_next - 1) mring[y & MCM] = (unsigned)M;
+        }
+        if (x + 1 < L) {
+            // virtual extension (PW:285-295) for the columns row x+1 reads beyond this band
+            const int wr_end = a_next + min(B, W - a_next);
+            for (int y = a + Bx + tid; y < wr_end; y += NT) {
+                if (y >= a_next - 1) {
+                    const unsigned g = (y < loaded_hi) ? ring[y & RCM].z : rec[y - lo].z;
+                    mring[y & MCM] = (unsigned)((int)(g - Gb) + ptot);
+                }
+            }
+            if (tid == 0 && a_next == a) mring[(a - 1) & MCM] = PWR_INF;   // PW:276: left of the band
+        } else {
+            // ---- entry column, PW:1352-1360: minimum over y in [ylow, W-1], ties -> largest y;
+            // every column past the band has the value of the last band cell (PW:287)
+            int ylow = max(-1, way[x] - H) + 1;
+            if (ylow > W - 1) ylow = W - 1;
+            unsigned key = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const int j = tid * C + i;
+                if (j < Bx && a + j >= ylow) key = min(key, (unsigned)Mv[i]);
+            }
+            const unsigned vmin = block_min_u32<NT>(key, red);
+            int cand = -1;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const int j = tid * C + i;
+                if (j < Bx && a + j >= ylow && (unsigned)Mv[i] == vmin) cand = a + j;
+            }
+            const int ybest = block_max_i32<NT>(cand, reinterpret_cast<int *>(red));
+            const bool beyond = (a + B <= W - 1);
+#pragma unroll
+            for (int i = 0; i < C; ++i)
+                if (tid * C + i == B - 1) red[0] = (unsigned)Mv[i];
+            __syncthreads();
+            if (tid == 0) {
+                int entry = ybest;
+                if (beyond && red[0] <= vmin) entry = W - 1;
+                m->entry = entry;
+            }
+        }
+        cells += (unsigned long long)Bx;
+        if ((x & 15) == 15 || x == L - 1) {
+            const int sh = 15 - (x & 15);
+            uint32_t *d = dirs + (size_t)(x >> 4) * NC + (size_t)tid * C;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                d[i] = ((accA[i] << sh) & 0xffffu) | (((accC[i] << sh) & 0xffffu) << 16);
+                accA[i] = accC[i] = 0;
+            }
+        }
+        __syncthreads();                                    // B2: row x published
+        a = a_next;
+    }
+    if (tid == 0) {
+        m->cells = cells;
+        atomicAdd(&st.hdr->cells_computed, cells);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trace: Backtracker (PW:1334-1454), one wave per job.  For DP row x at column y the ordered tests
+// (a)/(b) "left", (c) "diag", (d) "up" reduce to: walk left while bit A is set (cells past the band
+// are always "left", PW:285-295), then C decides between placing the base in column y (diag) and
+// opening a new column after y (up).  The wave looks at 256 cells of one 16-row group at a time.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_trace(DState st, JobBufs jb)
+{
+    const int job = blockIdx.x, lane = threadIdx.x;
+    JobMeta *m = &jb.meta[job];
+    const int L = m->L;
+    if (L <= 0 || !m->ok) return;
+    const int W = m->W, B = st.B, H = st.H, NC = jb.NC;
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+    int *newcol = jb.newcol + (size_t)job * jb.Lmax;
+
+    int x = L - 1, y = m->entry, err = 0, nnew = 0;
+    int gcur = -1, jb0 = 0;
+    uint32_t win[4] = {0, 0, 0, 0};
+    int gpre = -1, jbpre = 0;
+    uint32_t pre[4] = {0, 0, 0, 0};
+    while (x >= 0) {
+        const int a = max(0, way[x] - H);
+        const int Bx = min(B, W - a);
+        if (y < a) { err = 1; break; }                       // left of the band: unreachable (PW:276)
+        int j = min(y - a, Bx - 1);                          // past the band: implicit left moves
+        const int g = x >> 4, sh = 15 - (x & 15);
+        int found = -1, cbit = 0;
+        for (;;) {
+            if (g != gcur || j < jb0 || j > jb0 + 255) {
+                const int want = max(0, min(j - 191, NC - 256));
+                if (gpre == g && jbpre == want) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) win[q] = pre[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) win[q] = dirs[(size_t)g * NC + want + 64 * q + lane];
+                }
+                gcur = g; jb0 = want;
+                if (g > 0) {                                 // prefetch the same window of the next group
+                    gpre = g - 1; jbpre = want;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pre[q] = dirs[(size_t)(g - 1) * NC + want + 64 * q + lane];
+                }
+            }
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                if (found < 0) {
+                    const int cell = jb0 + 64 * q + lane;
+                    const bool abit = (win[q] >> sh) & 1u;
+                    const unsigned long long mk = __ballot(cell <= j && !abit);
+                    if (mk) {
+                        const int t = 63 - __builtin_clzll(mk);
+                        found = jb0 + 64 * q + t;
+                        const unsigned long long ck = __ballot((win[q] >> (16 + sh)) & 1u);
+                        cbit = (int)((ck >> t) & 1ull);
+                    }
+                }
+            }
+            if (found >= 0) break;
+            if (jb0 == 0) { err = 2; break; }
+            j = jb0 - 1;
+        }
+        if (err) break;
+        const int yy = a + found;
+        if (cbit) { if (lane == 0) newcol[x] = yy << 1; y = yy - 1; }             // PW:1394 (c)
+        else { if (lane == 0) newcol[x] = (yy << 1) | 1; y = yy; ++nnew; }        // PW:1404 (d)
+        --x;
+        if (x >= 0 && y < 0) { err = 3; break; }
+    }
+    if (lane == 0) {
+        m->nnew = nnew;
+        if (err) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// commit: apply one job's new placement to the resident state (one work-group):
+//   Column_Updater (PW:1222-1243) for every existing column the row touches, Column_Adder
+//   (PW:1245-1332) for every new column, then W_Con (PW:706-763): drop columns without a base and
+//   renumber.  AlGapCount of PW:1305-1314 ("rows non-blank on both sides of the new column") is
+//   coverage(y) - rows ending in y, both taken with the realigned row removed.
+// ---------------------------------------------------------------------------------------------
+#define COMMIT_NT 1024
+__device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_nf)
+{
+    const int tid = threadIdx.x;
+    Hdr *h = st.hdr;
+    JobMeta *m = &jb.meta[job];
+    const int L = m->L;
+    const int W = h->W;
+    const int cur = h->cur;
+    const int *order = cur ? st.order1 : st.order0;
+    int *norder = cur ? st.order0 : st.order1;
+    const int k = m->k;
+    const long long off = st.rowoff[k];
+    const int lo = m->lo;
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const int *newcol = jb.newcol + (size_t)job * jb.Lmax;
+    int *aux = jb.aux + (size_t)job * jb.Lmax;
+    const uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
+    uint8_t *mark2 = jb.mark2 + (size_t)job * jb.colcap;
+    const int way0 = way[0], wayL = way[L - 1];
+    const int nc0 = newcol[0], ncL = newcol[L - 1];
+    const int ny0 = (nc0 >> 1) + (nc0 & 1), nyL = ncL >> 1;   // existing columns inside the new row extent
+    const int nnew = m->nnew;
+    const int nfree = h->nfree, nslots = h->nslots;
+    const int take = min(nnew, nfree);
+    if (tid == 0) *s_nf = 0;
+    // 1. take the row out (PW:1172-1220)
+    for (int y = way0 + tid; y <= wayL; y += COMMIT_NT) {
+        Tally *t = &st.tally[order[y]];
+        const int mk = mark[y - lo];
+        const int sym = mk ? mk - 1 : 4;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) if (b != sym) t->w[b] -= 1;
+    }
+    if (tid == 0) st.tally[order[wayL]].endcnt -= 1;
+    for (int y = ny0 + tid; y <= nyL; y += COMMIT_NT) mark2[y - lo] = 0;
+    __syncthreads();
+    for (int x = tid; x < L; x += COMMIT_NT) {
+        const int c = newcol[x];
+        if (!(c & 1)) mark2[(c >> 1) - lo] = (uint8_t)(st.seq[off + x] + 1);
+    }
+    __syncthreads();
+    // 2. new columns (PW:1245-1332) and the slot of every base
+    unsigned carry = 0;
+    for (int base = 0; base < L; base += COMMIT_NT) {
+        const int x = base + tid;
+        const int c = (x < L) ? newcol[x] : 0;
+        const unsigned ins = (x < L && (c & 1)) ? 1u : 0u;
+        unsigned tot;
+        const unsigned incl = block_incl_add<COMMIT_NT>(ins, sh, tot);
+        const int idx = (int)(carry + incl - ins);
+        carry += tot;
+        if (x < L) {
+            const int y = c >> 1;
+            const int sloty = order[y];
+            if (ins) {
+                const int slot = (idx < take) ? st.freelist[nfree - 1 - idx] : nslots + (idx - take);
+                const int bs = st.seq[off + x];
+                const Tally ty = st.tally[sloty];
+                const uint32_t al = ty.w[5] - ty.endcnt;                          // PW:1305-1314
+                Tally nt;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) nt.w[b] = ((b != bs) ? 1u : 0u) + ((b != 4) ? al : 0u);   // PW:1320-1325
+                nt.endcnt = 0; nt.pad = 0;
+                st.tally[slot] = nt;
+                atomicAdd(&st.inscnt[y], 1);
+                aux[x] = slot;
+            } else {
+                aux[x] = sloty;
+            }
+        }
+    }
+    __syncthreads();
+    // 3. put the row back in its new place (PW:1222-1243)
+    for (int y = ny0 + tid; y <= nyL; y += COMMIT_NT) {
+        Tally *t = &st.tally[order[y]];
+        const int mk = mark2[y - lo];
+        const int sym = mk ? mk - 1 : 4;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) if (b != sym) t->w[b] += 1;
+    }
+    for (int x = tid; x < L; x += COMMIT_NT) st.pos[off + x] = aux[x];
+    __syncthreads();
+    if (tid == 0) st.tally[aux[L - 1]].endcnt += 1;
+    __syncthreads();
+    // 4. W_Con (PW:706-763) + splice: new ordinal of every surviving / new column
+    carry = 0;
+    for (int base = 0; base < W; base += COMMIT_NT) {
+        const int y = base + tid;
+        const bool valid = y < W;
+        const int slot = valid ? order[y] : 0;
+        const bool keep = valid && st.tally[slot].w[4] != 0;
+        const unsigned ic = valid ? (unsigned)st.inscnt[y] : 0u;
+        const unsigned cnt = (keep ? 1u : 0u) + ic;
+        unsigned tot;
+        const unsigned incl = block_incl_add<COMMIT_NT>(cnt, sh, tot);
+        const int idx = (int)(carry + incl - cnt);
+        carry += tot;
+        if (valid) {
+            st.newidx[y] = idx;
+            if (keep) { norder[idx] = slot; st.rank[slot] = idx; }
+            else { const int p = atomicAdd(s_nf, 1); st.freelist[nfree - take + p] = slot; }
+            if (ic) st.inscnt[y] = 0;
+        }
+    }
+    __syncthreads();
+    for (int x = tid; x < L; x += COMMIT_NT) {
+        const int c = newcol[x];
+        if (c & 1) {
+            const int y = c >> 1;
+            int t = 0;
+            for (int xx = x - 1; xx >= 0 && newcol[xx] == c; --xx) ++t;    // earlier bases opened there too
+            const int keepy = st.tally[order[y]].w[4] != 0 ? 1 : 0;
+            const int p = st.newidx[y] + keepy + t;
+            norder[p] = aux[x];
+            st.rank[aux[x]] = p;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        h->W = (int)carry;
+        h->nslots = nslots + (nnew - take);
+        h->nfree = nfree - take + *s_nf;
+        h->cur = cur ^ 1;
+        h->cells_reference += m->cells;
+        h->ncommitted += 1;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(COMMIT_NT) void k_commit(DState st, JobBufs jb, int job)
+{
+    __shared__ unsigned sh[COMMIT_NT / 64];
+    __shared__ int s_nf;
+    JobMeta *m = &jb.meta[job];
+    if (m->L <= 0 || !m->ok) return;
+    if (st.hdr->status != 0) return;
+    commit_job(st, jb, job, sh, &s_nf);
+}
+
+// ---------------------------------------------------------------------------------------------
+// total score (PW:864-892, PW:933-963): sum over columns of sum_b n_b * (cov - n_b), n_b = cov - w[b]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_score(DState st, unsigned long long *out)
+{
+    __shared__ unsigned long long sh[4];
+    const int W = st.hdr->W;
+    const int *order = cur_order(st);
+    unsigned long long s = 0;
+    for (int y = blockIdx.x * blockDim.x + threadIdx.x; y < W; y += gridDim.x * blockDim.x) {
+        const Tally t = st.tally[order[y]];
+#pragma unroll
+        for (int b = 0; b < 5; ++b) s += (unsigned long long)(t.w[5] - t.w[b]) * (unsigned long long)t.w[b];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// MMA_Auslesen (PW:1556-1598): one work-group per row writes "ACGT- " text
+__global__ __launch_bounds__(256) void k_export(DState st, unsigned char *out, int row0, int nrows, int W)
+{
+    const int r = row0 + blockIdx.x;
+    if (blockIdx.x >= nrows) return;
+    unsigned char *o = out + (size_t)blockIdx.x * W;
+    const int L = st.rowlen[r];
+    const long long off = st.rowoff[r];
+    for (int y = threadIdx.x; y < W; y += blockDim.x) o[y] = ' ';
+    __syncthreads();
+    if (L == 0) return;
+    const int s = st.rank[st.pos[off]], e = st.rank[st.pos[off + L - 1]];
+    for (int y = s + threadIdx.x; y <= e; y += blockDim.x) o[y] = '-';
+    __syncthreads();
+    for (int x = threadIdx.x; x < L; x += blockDim.x) o[st.rank[st.pos[off + x]]] = "ACGT"[st.seq[off + x]];
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+#define HIPC(call)                                                                     \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "pwr: %s failed: %s\n", #call, hipGetErrorString(e_));    \
+            return PWR_ERR_DEVICE;                                                     \
+        }                                                                              \
+    } while (0)
+
+struct pwr_ctx {
+    int T = 0, B = 0, H = 0, device = 0;
+    // host-side text (valid while !on_device)
+    int W_host = 0;
+    std::vector<unsigned char> text;      // symbol codes 0..5, row-major T x W_host
+    bool on_device = false;
+    // device
+    DState st{};
+    JobBufs jb{};
+    int njobs = 0;
+    int *d_jobrows = nullptr;
+    int *d_rowids = nullptr;              // [T] identity: job j of a window starting at row k0 realigns d_rowids[k0 + j]
+    unsigned long long *d_score = nullptr;
+    hipStream_t stream = nullptr;
+    std::vector<int> rowlen;
+    long long sumL = 0;
+    int Lmax = 0;
+    int W_ub = 0;                         // host upper bound of the device width
+    int nslots_ub = 0;
+    // options
+    int window = 1;
+    int profile = 0;
+    int threads = 1024;
+    int cells_per_thread = 1;
+    // stats
+    pwr_stats stats{};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    // all device allocations, for cleanup
+    std::vector<void *> allocs;
+};
+
+static int code_of_char(unsigned char c)
+{
+    switch (c) {   // PW:165-222
+    case 'a': case 'A': return 0;
+    case 'c': case 'C': return 1;
+    case 'g': case 'G': return 2;
+    case 't': case 'T': return 3;
+    case '-': case '_': return 4;
+    case ' ': return 5;
+    default: return -1;
+    }
+}
+
+extern "C" const char *pwr_strerror(int code)
+{
+    switch (code) {
+    case PWR_OK: return "ok";
+    case PWR_ERR_ARG: return "bad argument";
+    case PWR_ERR_NOMEM: return "out of memory";
+    case PWR_ERR_DEVICE: return "HIP device error";
+    case PWR_ERR_INPUT: return "malformed MSA input";
+    case PWR_ERR_RANGE: return "limit exceeded (sequence length, bandwidth or 32-bit score range)";
+    case PWR_ERR_INTERNAL: return "inconsistent traceback";
+    case PWR_ERR_UNSUPPORTED: return "MSA state not representable on the device (untrimmed or blanks between bases)";
+    case PWR_ERR_IO: return "cannot open output file";
+    default: return "unknown error";
+    }
+}
+
+extern "C" int pwr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return PWR_ERR_DEVICE;
+    return n;
+}
+
+extern "C" int pwr_create(pwr_ctx **out, int rows, int width, const unsigned char *text, int bandwidth, int device)
+{
+    if (!out || !text || rows <= 0 || width <= 0) return PWR_ERR_ARG;
+    if (bandwidth < 1 || bandwidth > PWR_MAX_BANDWIDTH) return PWR_ERR_RANGE;
+    pwr_ctx *c = new (std::nothrow) pwr_ctx();
+    if (!c) return PWR_ERR_NOMEM;
+    c->T = rows; c->B = bandwidth; c->H = bandwidth / 2; c->device = device;   // PW:1625-1626
+    c->W_host = width;
+    try { c->text.resize((size_t)rows * width); } catch (...) { delete c; return PWR_ERR_NOMEM; }
+    for (size_t i = 0; i < (size_t)rows * width; ++i) {
+        const int s = code_of_char(text[i]);
+        if (s < 0) { delete c; return PWR_ERR_INPUT; }
+        c->text[i] = (unsigned char)s;
+    }
+    *out = c;
+    return PWR_OK;
+}
+
+static void free_device(pwr_ctx *c)
+{
+    for (void *p : c->allocs) (void)hipFree(p);
+    c->allocs.clear();
+    for (auto &e : c->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    c->ev_pool.clear();
+    c->ev_used = 0;
+    if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
+    c->on_device = false;
+}
+
+extern "C" void pwr_destroy(pwr_ctx *c)
+{
+    if (!c) return;
+    if (c->on_device || !c->allocs.empty()) { (void)hipSetDevice(c->device); free_device(c); }
+    delete c;
+}
+
+template <typename T>
+static int dmalloc(pwr_ctx *c, T **p, size_t n)
+{
+    void *q = nullptr;
+    if (hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return PWR_ERR_NOMEM;
+    c->allocs.push_back(q);
+    *p = reinterpret_cast<T *>(q);
+    return PWR_OK;
+}
+static void dfree(pwr_ctx *c, void *p)
+{
+    if (!p) return;
+    for (size_t i = 0; i < c->allocs.size(); ++i)
+        if (c->allocs[i] == p) { c->allocs.erase(c->allocs.begin() + i); break; }
+    (void)hipFree(p);
+}
+
+// Host EntAlGapper (PW:459-645) on the code matrix.  A '-' turns blank when the row is blank in the
+// previous surviving column (or there is none); surviving = the column holds a base in some row.
+// The test only ever looks at the same row, so each row is swept on its own, left-to-right and then
+// right-to-left, over the surviving columns.
+static void host_trim(pwr_ctx *c)
+{
+    const int T = c->T, W = c->W_host;
+    std::vector<unsigned char> has(W, 0);
+    for (int r = 0; r < T; ++r) {
+        const unsigned char *row = &c->text[(size_t)r * W];
+        for (int i = 0; i < W; ++i) has[i] |= (row[i] < 4);
+    }
+    std::vector<int> keep;
+    keep.reserve(W);
+    for (int i = 0; i < W; ++i) if (has[i]) keep.push_back(i);
+    const int n = (int)keep.size();
+    std::vector<unsigned char> nt((size_t)T * n);
+    for (int r = 0; r < T; ++r) {
+        const unsigned char *row = &c->text[(size_t)r * W];
+        unsigned char *o = &nt[(size_t)r * n];
+        bool prev_blank = true;
+        for (int i = 0; i < n; ++i) {
+            unsigned char s = row[keep[i]];
+            if (s == 4 && prev_blank) s = 5;
+            prev_blank = (s == 5);
+            o[i] = s;
+        }
+        bool next_blank = true;
+        for (int i = n - 1; i >= 0; --i) {
+            if (o[i] == 4 && next_blank) o[i] = 5;
+            next_blank = (o[i] == 5);
+        }
+    }
+    c->text.swap(nt);
+    c->W_host = n;
+}
+
+static int alloc_jobs(pwr_ctx *c, int njobs)
+{
+    JobBufs &jb = c->jb;
+    const int NC = c->threads * c->cells_per_thread;
+    jb.Lmax = std::max(c->Lmax, 1);
+    jb.colcap = c->st.colcap;
+    jb.NC = NC;
+    jb.dirstride = (size_t)((jb.Lmax + 15) / 16) * NC;
+    int rc;
+    if ((rc = dmalloc(c, &jb.meta, njobs))) return rc;
+    if ((rc = dmalloc(c, &jb.way, (size_t)njobs * jb.Lmax))) return rc;
+    if ((rc = dmalloc(c, &jb.rec, (size_t)njobs * jb.colcap))) return rc;
+    if ((rc = dmalloc(c, &jb.mark, (size_t)njobs * jb.colcap))) return rc;
+    if ((rc = dmalloc(c, &jb.mark2, (size_t)njobs * jb.colcap))) return rc;
+    if ((rc = dmalloc(c, &jb.dirs, (size_t)njobs * jb.dirstride))) return rc;
+    if ((rc = dmalloc(c, &jb.newcol, (size_t)njobs * jb.Lmax))) return rc;
+    if ((rc = dmalloc(c, &jb.aux, (size_t)njobs * jb.Lmax))) return rc;
+    if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
+    if (hipMemset(jb.meta, 0, sizeof(JobMeta) * njobs) != hipSuccess) return PWR_ERR_DEVICE;
+    c->njobs = njobs;
+    return PWR_OK;
+}
+
+static void free_jobs(pwr_ctx *c)
+{
+    JobBufs &jb = c->jb;
+    dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.rec); dfree(c, jb.mark); dfree(c, jb.mark2);
+    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, c->d_jobrows);
+    jb = JobBufs{};
+    c->d_jobrows = nullptr;
+    c->njobs = 0;
+}
+
+// Build the device state from the host code matrix.  Requires canonical rows.
+static int upload(pwr_ctx *c)
+{
+    if (c->on_device) return PWR_OK;
+    const int T = c->T, W0 = c->W_host;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    // drop columns without a base (what the first W_Con, PW:706-763, does) and check the rows
+    std::vector<uint32_t> w((size_t)W0 * 6, 0);
+    std::vector<long long> rowoff(T + 1, 0);
+    c->rowlen.assign(T, 0);
+    for (int r = 0; r < T; ++r) {
+        const unsigned char *row = &c->text[(size_t)r * W0];
+        int first = -1, last = -1, L = 0;
+        for (int i = 0; i < W0; ++i) {
+            const int s = row[i];
+            if (s < 4) { if (first < 0) first = i; last = i; ++L; }
+            if (s != 5) for (int b = 0; b < 6; ++b) if (b != s) w[(size_t)i * 6 + b] += 1;
+        }
+        for (int i = 0; i < W0; ++i) {
+            const int s = row[i];
+            const bool inside = first >= 0 && i >= first && i <= last;
+            if (inside ? (s == 5) : (s != 5)) return PWR_ERR_UNSUPPORTED;
+        }
+        if (L > PWR_MAX_SEQ_LENGTH) return PWR_ERR_RANGE;                     // PW:675-680
+        c->rowlen[r] = L;
+        rowoff[r + 1] = rowoff[r] + L;
+    }
+    c->sumL = rowoff[T];
+    c->Lmax = 0;
+    for (int r = 0; r < T; ++r) c->Lmax = std::max(c->Lmax, c->rowlen[r]);
+    std::vector<int> colidx(W0, -1);
+    int W = 0;
+    for (int i = 0; i < W0; ++i) if (w[(size_t)i * 6 + 4] != 0) colidx[i] = W++;
+    if (W == 0) W = 0;
+    std::vector<Tally> tal(std::max(W, 1));
+    memset(tal.data(), 0, sizeof(Tally) * tal.size());
+    for (int i = 0; i < W0; ++i)
+        if (colidx[i] >= 0) for (int b = 0; b < 6; ++b) tal[colidx[i]].w[b] = w[(size_t)i * 6 + b];
+    std::vector<uint8_t> seq(std::max<long long>(c->sumL, 1));
+    std::vector<int> pos(std::max<long long>(c->sumL, 1));
+    for (int r = 0; r < T; ++r) {
+        const unsigned char *row = &c->text[(size_t)r * W0];
+        long long o = rowoff[r];
+        int last = -1;
+        for (int i = 0; i < W0; ++i)
+            if (row[i] < 4) { seq[o] = row[i]; pos[o] = colidx[i]; last = colidx[i]; ++o; }
+        if (last >= 0) tal[last].endcnt += 1;
+    }
+    // capacities
+    DState &st = c->st;
+    st = DState{};
+    st.T = T; st.B = c->B; st.H = c->H; st.Lmax = c->Lmax;
+    st.colcap = 2 * W + 2 * c->Lmax + 8192;
+    st.slotcap = st.colcap;
+    int rc;
+    Hdr hdr{};
+    hdr.W = W; hdr.nslots = W; hdr.nfree = 0; hdr.cur = 0;
+    long long *d_rowoff; int *d_rowlen; uint8_t *d_seq;
+    if ((rc = dmalloc(c, &st.hdr, 1))) return rc;
+    if ((rc = dmalloc(c, &d_rowoff, T + 1))) return rc;
+    if ((rc = dmalloc(c, &d_rowlen, T))) return rc;
+    if ((rc = dmalloc(c, &d_seq, seq.size()))) return rc;
+    if ((rc = dmalloc(c, &st.pos, pos.size()))) return rc;
+    if ((rc = dmalloc(c, &st.tally, st.slotcap))) return rc;
+    if ((rc = dmalloc(c, &st.order0, st.colcap))) return rc;
+    if ((rc = dmalloc(c, &st.order1, st.colcap))) return rc;
+    if ((rc = dmalloc(c, &st.rank, st.slotcap))) return rc;
+    if ((rc = dmalloc(c, &st.freelist, st.slotcap))) return rc;
+    if ((rc = dmalloc(c, &st.inscnt, st.colcap))) return rc;
+    if ((rc = dmalloc(c, &st.newidx, st.colcap))) return rc;
+    if ((rc = dmalloc(c, &c->d_score, 1))) return rc;
+    st.rowoff = d_rowoff; st.rowlen = d_rowlen; st.seq = d_seq;
+    std::vector<int> ident(std::max(W, 1));
+    for (int i = 0; i < W; ++i) ident[i] = i;
+    HIPC(hipMemcpy(st.hdr, &hdr, sizeof hdr, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_rowoff, rowoff.data(), sizeof(long long) * (T + 1), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_rowlen, c->rowlen.data(), sizeof(int) * T, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(d_seq, seq.data(), seq.size(), hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(st.pos, pos.data(), sizeof(int) * pos.size(), hipMemcpyHostToDevice));
+    HIPC(hipMemset(st.tally, 0, sizeof(Tally) * st.slotcap));
+    HIPC(hipMemcpy(st.tally, tal.data(), sizeof(Tally) * W, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(st.order0, ident.data(), sizeof(int) * W, hipMemcpyHostToDevice));
+    HIPC(hipMemcpy(st.rank, ident.data(), sizeof(int) * W, hipMemcpyHostToDevice));
+    HIPC(hipMemset(st.inscnt, 0, sizeof(int) * st.colcap));
+    {
+        std::vector<int> ids(T);
+        for (int r = 0; r < T; ++r) ids[r] = r;
+        if ((rc = dmalloc(c, &c->d_rowids, T))) return rc;
+        HIPC(hipMemcpy(c->d_rowids, ids.data(), sizeof(int) * T, hipMemcpyHostToDevice));
+    }
+    HIPC(hipStreamCreate(&c->stream));
+    if ((rc = alloc_jobs(c, std::max(1, c->window)))) return rc;
+    c->W_ub = W; c->nslots_ub = W;
+    c->on_device = true;
+    std::vector<unsigned char>().swap(c->text);
+    c->W_host = 0;
+    return PWR_OK;
+}
+
+static int read_hdr(pwr_ctx *c, Hdr *h)
+{
+    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpy(h, c->st.hdr, sizeof(Hdr), hipMemcpyDeviceToHost));
+    return PWR_OK;
+}
+
+// grow a device array, keeping its first `keep` elements
+template <typename T>
+static int regrow(pwr_ctx *c, T **p, size_t keep, size_t ncap)
+{
+    T *q;
+    int rc = dmalloc(c, &q, ncap);
+    if (rc) return rc;
+    if (hipMemset(q, 0, ncap * sizeof(T)) != hipSuccess) return PWR_ERR_DEVICE;
+    if (keep && hipMemcpy(q, *p, keep * sizeof(T), hipMemcpyDeviceToDevice) != hipSuccess) return PWR_ERR_DEVICE;
+    dfree(c, *p);
+    *p = q;
+    return PWR_OK;
+}
+
+// Make sure the next `rows_ahead` commits (each adds at most Lmax columns / slots) fit.
+static int ensure_capacity(pwr_ctx *c, long long growth)
+{
+    if ((long long)c->W_ub + growth + 64 <= c->st.colcap && (long long)c->nslots_ub + growth + 64 <= c->st.slotcap)
+        return PWR_OK;
+    Hdr h;
+    int rc = read_hdr(c, &h);
+    if (rc) return rc;
+    if (h.status) return h.status;
+    c->W_ub = h.W; c->nslots_ub = h.nslots;
+    if ((long long)h.W + growth + 64 <= c->st.colcap && (long long)h.nslots + growth + 64 <= c->st.slotcap)
+        return PWR_OK;
+    DState &st = c->st;
+    const size_t ncap = (size_t)std::max<long long>(2LL * st.colcap, (long long)std::max(h.W, h.nslots) + 2 * growth + 8192);
+    const size_t ocol = st.colcap, oslot = st.slotcap;
+    if ((rc = regrow(c, &st.tally, oslot, ncap))) return rc;
+    if ((rc = regrow(c, &st.order0, ocol, ncap))) return rc;
+    if ((rc = regrow(c, &st.order1, ocol, ncap))) return rc;
+    if ((rc = regrow(c, &st.rank, oslot, ncap))) return rc;
+    if ((rc = regrow(c, &st.freelist, oslot, ncap))) return rc;
+    if ((rc = regrow(c, &st.inscnt, 0, ncap))) return rc;
+    if ((rc = regrow(c, &st.newidx, 0, ncap))) return rc;
+    st.colcap = (int)ncap; st.slotcap = (int)ncap;
+    const int nj = c->njobs;
+    free_jobs(c);
+    return alloc_jobs(c, nj);
+}
+
+static int launch_fill(pwr_ctx *c, int njobs)
+{
+    const int NT = c->threads, C = c->cells_per_thread, NC = NT * C;
+    const size_t lds = (size_t)4 * NC * 16 + (size_t)2 * NC * 4 + 16 * 4 + 64 * 4;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profile) {
+        if (c->ev_used == c->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIPC(hipEventCreate(&a)); HIPC(hipEventCreate(&b));
+            c->ev_pool.emplace_back(a, b);
+        }
+        e0 = c->ev_pool[c->ev_used].first; e1 = c->ev_pool[c->ev_used].second;
+        c->ev_used++;
+        HIPC(hipEventRecord(e0, c->stream));
+    }
+    if (NT == 1024 && C == 1) hipLaunchKernelGGL((k_fill<1024, 1>), dim3(njobs), dim3(1024), lds, c->stream, c->st, c->jb);
+    else if (NT == 512 && C == 2) hipLaunchKernelGGL((k_fill<512, 2>), dim3(njobs), dim3(512), lds, c->stream, c->st, c->jb);
+    else if (NT == 1024 && C == 2) hipLaunchKernelGGL((k_fill<1024, 2>), dim3(njobs), dim3(1024), lds, c->stream, c->st, c->jb);
+    else if (NT == 256 && C == 4) hipLaunchKernelGGL((k_fill<256, 4>), dim3(njobs), dim3(256), lds, c->stream, c->st, c->jb);
+    else return PWR_ERR_ARG;
+    HIPC(hipGetLastError());
+    if (c->profile) HIPC(hipEventRecord(e1, c->stream));
+    c->stats.fill_launches += 1;
+    return PWR_OK;
+}
+
+static int drain_events(pwr_ctx *c)
+{
+    if (!c->ev_used) return PWR_OK;
+    HIPC(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->ev_used; ++i) {
+        float ms = 0;
+        HIPC(hipEventElapsedTime(&ms, c->ev_pool[i].first, c->ev_pool[i].second));
+        c->stats.fill_ms += ms;
+    }
+    c->ev_used = 0;
+    return PWR_OK;
+}
+
+static int configure_kernels(pwr_ctx *c)
+{
+    static bool done = false;
+    if (done) return PWR_OK;
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<1024, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<256, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    done = true;
+    return PWR_OK;
+}
+
+// choose threads / cells per thread so that the band fits: NT*C >= B
+static int pick_geometry(pwr_ctx *c)
+{
+    if (c->B <= 1024) { if (c->threads != 512 && c->threads != 256) c->threads = 1024; }
+    else c->threads = 1024;
+    c->cells_per_thread = 1;
+    while (c->threads * c->cells_per_thread < c->B) c->cells_per_thread *= 2;
+    if (c->threads == 512 && c->cells_per_thread < 2) c->cells_per_thread = 2;
+    if (c->threads == 256 && c->cells_per_thread < 4) c->cells_per_thread = 4;
+    if (c->threads == 256 && c->cells_per_thread > 4) { c->threads = 1024; c->cells_per_thread = c->B > 1024 ? 2 : 1; }
+    if (c->threads == 512 && c->cells_per_thread > 2) { c->threads = 1024; c->cells_per_thread = 2; }
+    return PWR_OK;
+}
+
+static int ensure_device(pwr_ctx *c)
+{
+    if (c->on_device) { if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE; return PWR_OK; }
+    pick_geometry(c);
+    int rc = upload(c);
+    if (rc) { free_device(c); return rc; }
+    return configure_kernels(c);
+}
+
+// one row, sequential: gather -> fill -> trace -> commit on the stream, no host sync
+static int enqueue_row(pwr_ctx *c, int k)
+{
+    if (c->rowlen[k] == 0) return PWR_OK;                                      // PW:1488
+    int rc = ensure_capacity(c, c->rowlen[k]);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gather, dim3(1), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids + k);
+    if ((rc = launch_fill(c, 1))) return rc;
+    hipLaunchKernelGGL(k_trace, dim3(1), dim3(64), 0, c->stream, c->st, c->jb);
+    hipLaunchKernelGGL(k_commit, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, 0);
+    HIPC(hipGetLastError());
+    c->W_ub += c->rowlen[k];
+    c->nslots_ub += c->rowlen[k];
+    c->stats.rows_committed += 1;
+    return PWR_OK;
+}
+
+static int check_status(pwr_ctx *c)
+{
+    Hdr h;
+    int rc = read_hdr(c, &h);
+    if (rc) return rc;
+    c->W_ub = h.W; c->nslots_ub = h.nslots;
+    c->stats.cells_computed = h.cells_computed;
+    c->stats.cells_reference = h.cells_reference;
+    if ((rc = drain_events(c))) return rc;
+    return h.status;
+}
+
+extern "C" int pwr_realign_row(pwr_ctx *c, int k)
+{
+    if (!c || k < 0 || k >= c->T) return PWR_ERR_ARG;
+    int rc = ensure_device(c);
+    if (rc) return rc;
+    if ((rc = enqueue_row(c, k))) return rc;
+    return check_status(c);
+}
+
+extern "C" int pwr_realign_round(pwr_ctx *c)
+{
+    if (!c) return PWR_ERR_ARG;
+    int rc = ensure_device(c);
+    if (rc) return rc;
+    for (int k = 0; k < c->T; ++k) {                                           // PW:1695: rows in input order
+        if ((rc = enqueue_row(c, k))) return rc;
+        if (c->profile && c->ev_used >= 2048) { if ((rc = drain_events(c))) return rc; }
+    }
+    return check_status(c);
+}
+
+extern "C" int pwr_total_score(pwr_ctx *c, uint64_t *total)
+{
+    if (!c || !total) return PWR_ERR_ARG;
+    if (!c->on_device) {
+        // host state (before the first device call): literal PW:864-892 on the code matrix
+        const int T = c->T, W = c->W_host;
+        std::vector<uint32_t> w((size_t)W * 6, 0);
+        for (int r = 0; r < T; ++r)
+            for (int i = 0; i < W; ++i) {
+                const int s = c->text[(size_t)r * W + i];
+                if (s != 5) for (int b = 0; b < 6; ++b) if (b != s) w[(size_t)i * 6 + b] += 1;
+            }
+        uint64_t tot = 0;
+        for (int i = 0; i < W; ++i)
+            for (int b = 0; b < 5; ++b) tot += (uint64_t)(w[(size_t)i * 6 + 5] - w[(size_t)i * 6 + b]) * w[(size_t)i * 6 + b];
+        *total = tot;
+        return PWR_OK;
+    }
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    HIPC(hipMemsetAsync(c->d_score, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_score, dim3(256), dim3(256), 0, c->stream, c->st, c->d_score);
+    unsigned long long v = 0;
+    HIPC(hipMemcpyAsync(&v, c->d_score, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    *total = v;
+    return PWR_OK;
+}
+
+extern "C" int pwr_dims(pwr_ctx *c, int *rows, int *width)
+{
+    if (!c) return PWR_ERR_ARG;
+    if (rows) *rows = c->T;
+    if (width) {
+        if (!c->on_device) *width = c->W_host;
+        else {
+            if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+            Hdr h;
+            int rc = read_hdr(c, &h);
+            if (rc) return rc;
+            *width = h.W;
+        }
+    }
+    return PWR_OK;
+}
+
+extern "C" int pwr_export_rows(pwr_ctx *c, unsigned char *buf, size_t cap)
+{
+    static const char chars[6] = {'A', 'C', 'G', 'T', '-', ' '};              // PW:1558-1563
+    if (!c || !buf) return PWR_ERR_ARG;
+    if (!c->on_device) {
+        const size_t n = (size_t)c->T * c->W_host;
+        if (cap < n) return PWR_ERR_ARG;
+        for (size_t i = 0; i < n; ++i) buf[i] = (unsigned char)chars[c->text[i]];
+        return PWR_OK;
+    }
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    Hdr h;
+    int rc = read_hdr(c, &h);
+    if (rc) return rc;
+    const int W = h.W;
+    if (cap < (size_t)c->T * W) return PWR_ERR_ARG;
+    if (W == 0) return PWR_OK;
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)c->T, ((size_t)512 << 20) / (size_t)W));
+    unsigned char *d = nullptr;
+    if ((rc = dmalloc(c, &d, (size_t)chunk * W))) return rc;
+    for (int r0 = 0; r0 < c->T; r0 += chunk) {
+        const int nr = std::min(chunk, c->T - r0);
+        hipLaunchKernelGGL(k_export, dim3(nr), dim3(256), 0, c->stream, c->st, d, r0, nr, W);
+        HIPC(hipMemcpyAsync(buf + (size_t)r0 * W, d, (size_t)nr * W, hipMemcpyDeviceToHost, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));
+    }
+    dfree(c, d);
+    return PWR_OK;
+}
+
+extern "C" int pwr_trim_ends(pwr_ctx *c)
+{
+    if (!c) return PWR_ERR_ARG;
+    if (!c->on_device) { host_trim(c); return PWR_OK; }
+    // Device state: every row is blank* (base|'-')* blank* with bases at both ends and every
+    // column holds a base (the commit compacts), so EntAlGapper cannot change anything
+    // (PW:483-507 only fires on a '-' next to a blank or at an MSA edge).
+    return PWR_OK;
+}
+
+extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
+{
+    if (!c || !key) return PWR_ERR_ARG;
+    if (!strcmp(key, "window")) { if (value < 1 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
+    if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
+    if (!strcmp(key, "threads")) {
+        if (c->on_device || (value != 256 && value != 512 && value != 1024)) return PWR_ERR_ARG;
+        c->threads = (int)value;
+        return PWR_OK;
+    }
+    return PWR_ERR_ARG;
+}
+
+extern "C" int pwr_get_stats(pwr_ctx *c, pwr_stats *out)
+{
+    if (!c || !out) return PWR_ERR_ARG;
+    if (c->on_device) {
+        if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+        int rc = check_status(c);
+        if (rc) return rc;
+    }
+    *out = c->stats;
+    return PWR_OK;
+}
+
+extern "C" int pwr_reset_stats(pwr_ctx *c)
+{
+    if (!c) return PWR_ERR_ARG;
+    c->stats = pwr_stats{};
+    if (c->on_device) {
+        if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+        HIPC(hipStreamSynchronize(c->stream));
+        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 2 * sizeof(unsigned long long)));
+    }
+    return PWR_OK;
+}
+
+// ---- introspection for kernel-level parity tests (tests/ only) ----
+extern "C" int pwr_debug_last_job(pwr_ctx *c, int *L, int *entry, int *W, int *way, int *newcol, int cap)
+{
+    if (!c || !c->on_device) return PWR_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    HIPC(hipStreamSynchronize(c->stream));
+    JobMeta m;
+    HIPC(hipMemcpy(&m, c->jb.meta, sizeof m, hipMemcpyDeviceToHost));
+    if (L) *L = m.L;
+    if (entry) *entry = m.entry;
+    if (W) *W = m.W;
+    const int n = std::min(cap, m.L);
+    if (way && n > 0) HIPC(hipMemcpy(way, c->jb.way, sizeof(int) * n, hipMemcpyDeviceToHost));
+    if (newcol && n > 0) HIPC(hipMemcpy(newcol, c->jb.newcol, sizeof(int) * n, hipMemcpyDeviceToHost));
+    return PWR_OK;
+}

@@ -1,0 +1,158 @@
+"""Host-side mirror of the reference's PW_ReAligner interface on top of the C ABI (include/pwr.h).
+
+The reference has no Python API; its interface is `./PW_ReAligner <MSA> [-o out] [-b bw]`
+(PW_ReAligner.c:1610-1647) and, inside, the functions this class names its methods after.
+All work happens in libpwr.so (HIP); nothing here computes."""
+import ctypes
+import io
+import os
+import subprocess
+
+from . import _lib
+
+
+class PwrError(RuntimeError):
+    def __init__(self, code, what):
+        super().__init__(f"{what}: {_lib.load().pwr_strerror(code).decode()} ({code})")
+        self.code = code
+
+
+def _check(code, what):
+    if code != 0:
+        raise PwrError(code, what)
+
+
+class PWReAligner:
+    """One MSA resident on one GPU.  rows: list of equal-length bytes over `acgtACGT-_ `."""
+
+    def __init__(self, rows, bandwidth=1000, device=0, window=None, profile=False, threads=None):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        self.T = len(rows)
+        width = len(rows[0]) if rows else 0
+        if any(len(r) != width for r in rows):
+            raise ValueError("all MSA rows must have the same length")
+        _check(self._lib.pwr_create(ctypes.byref(self._h), self.T, width, b"".join(rows), bandwidth, device),
+               "pwr_create")
+        if window is not None:
+            _check(self._lib.pwr_set_option(self._h, b"window", int(window)), "set window")
+        if threads is not None:
+            _check(self._lib.pwr_set_option(self._h, b"threads", int(threads)), "set threads")
+        if profile:
+            _check(self._lib.pwr_set_option(self._h, b"profile", 1), "set profile")
+
+    @classmethod
+    def from_file(cls, path, **kw):
+        with open(path, "rb") as f:
+            data = f.read()
+        rows = data.split(b"\n")
+        if rows[-1] != b"":
+            raise ValueError("last line is not newline-terminated")       # PW_ReAligner.c:134
+        return cls(rows[:-1], **kw)
+
+    def close(self):
+        if self._h:
+            self._lib.pwr_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def trim_ends(self):                     # EntAlGapper, PW_ReAligner.c:459-645
+        _check(self._lib.pwr_trim_ends(self._h), "pwr_trim_ends")
+
+    def realign_row(self, k):                # Matrix_Filler(k), PW_ReAligner.c:1469-1531
+        _check(self._lib.pwr_realign_row(self._h, k), "pwr_realign_row")
+
+    def realign_round(self):                 # PW_ReAligner.c:1695-1737
+        _check(self._lib.pwr_realign_round(self._h), "pwr_realign_round")
+
+    def total_score(self) -> int:            # OverallScorePrint, PW_ReAligner.c:933-963
+        v = ctypes.c_uint64()
+        _check(self._lib.pwr_total_score(self._h, ctypes.byref(v)), "pwr_total_score")
+        return v.value
+
+    def dims(self):
+        t, w = ctypes.c_int(), ctypes.c_int()
+        _check(self._lib.pwr_dims(self._h, ctypes.byref(t), ctypes.byref(w)), "pwr_dims")
+        return t.value, w.value
+
+    def export_rows(self):                   # MMA_Auslesen, PW_ReAligner.c:1556-1598
+        t, w = self.dims()
+        buf = ctypes.create_string_buffer(t * w + 1)
+        _check(self._lib.pwr_export_rows(self._h, buf, t * w), "pwr_export_rows")
+        raw = buf.raw[:t * w]
+        return [raw[i * w:(i + 1) * w] for i in range(t)]
+
+    def stats(self):
+        s = _lib.PwrStats()
+        _check(self._lib.pwr_get_stats(self._h, ctypes.byref(s)), "pwr_get_stats")
+        return {f: getattr(s, f) for f, _ in s._fields_}
+
+    def reset_stats(self):
+        _check(self._lib.pwr_reset_stats(self._h), "pwr_reset_stats")
+
+    def debug_last_job(self, cap=40000):
+        L, e, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        way = (ctypes.c_int * cap)()
+        nc = (ctypes.c_int * cap)()
+        _check(self._lib.pwr_debug_last_job(self._h, ctypes.byref(L), ctypes.byref(e), ctypes.byref(w), way, nc, cap),
+               "pwr_debug_last_job")
+        n = L.value
+        return {"L": n, "entry": e.value, "W": w.value, "way": list(way[:n]), "newcol": list(nc[:n])}
+
+    # ---- the whole program, PW_ReAligner.c:1610-1759 ----
+    def run(self, out_path, max_rounds=-1, log=None):
+        """Round loop of main(): returns the list of totals printed; writes out_path after every
+        improving round."""
+        def score_line(total):
+            m, u = (0, 0) if total == 0 else ((total - 1) // 1000000, (total - 1) % 1000000 + 1)
+            return "OverallScore: %d%06d" % (m, u)
+        lines = []
+
+        def emit(s):
+            lines.append(s)
+            if log is not None:
+                print(s, file=log, flush=True)
+        self.trim_ends()
+        t, w = self.dims()
+        emit("Rows %d, Columns %d." % (t, w))
+        best = self.total_score()
+        emit(score_line(best))
+        rounds = 0
+        while rounds < 10000 and (max_rounds < 0 or rounds < max_rounds):
+            self.realign_round()
+            rounds += 1
+            tot = self.total_score()
+            emit(score_line(tot))
+            if tot < best:
+                best = tot
+                write_msa(out_path, self.export_rows())
+            else:
+                break
+        self.trim_ends()
+        tot = self.total_score()
+        emit(score_line(tot))
+        if tot < best:
+            write_msa(out_path, self.export_rows())
+        return lines
+
+
+def write_msa(path, rows):
+    with open(path, "wb") as f:
+        f.write(b"\n".join(rows) + b"\n")
+
+
+def run_file(in_path, out_path="MSAreal", bandwidth=1000, device=0, max_rounds=-1):
+    """pwr_run_file through the C ABI; returns (exit_code, stdout lines)."""
+    cli = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "PW_ReAligner")
+    if not os.path.exists(cli):
+        raise RuntimeError(f"{cli} is missing: build it first (make -C repeatresolver_amd/csrc)")
+    args = [cli, in_path, "-o", out_path, "-b", str(bandwidth), "-g", str(device)]
+    if max_rounds >= 0:
+        args += ["-r", str(max_rounds)]
+    p = subprocess.run(args, capture_output=True)
+    return p.returncode, p.stdout.decode("latin1").splitlines()
