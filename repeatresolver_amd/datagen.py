@@ -259,6 +259,9 @@ CONFIGS = {
                        length_scale=0.25, min_aligned=200, seed=12),
     "toy_c": SimConfig(kind="Tree", copies=40, coverage=25, difference=0.01, repeat_len=1000, flank=300,
                        length_scale=0.05, min_aligned=100, seed=13),
+    # mid-size shape for profiling runs (about 1/10 of the default in every dimension)
+    "tree_medium": SimConfig(kind="Tree", copies=24, coverage=30, difference=0.01, repeat_len=10000, flank=3500,
+                             length_scale=0.35, min_aligned=350, seed=15),
     # transposon-sized stand-in for configs[4] (real Drosophila files are not available offline)
     "transposon_like": SimConfig(kind="Distributed", copies=30, coverage=20, difference=0.02,
                                  repeat_len=5000, flank=2000, length_scale=0.3, min_aligned=300, seed=14),
