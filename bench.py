@@ -109,6 +109,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     st = g.stats()
+    clk_mhz, _ = g.debug_fill_clock()
     score1 = g.total_score()
     _, W1 = g.dims()
 
@@ -143,7 +144,8 @@ def main():
                                    f"one step = one realignment round",
                        "rows": T, "columns_in": W0, "columns_now": W1, "bandwidth": args.bandwidth,
                        "window": args.window, "score_before": score0, "score_after": score1,
-                       "rows_committed": st["rows_committed"], "rows_recomputed": st["rows_recomputed"],
+                       "rows_committed": st["rows_committed"], "rows_recomputed": st["rows_recomputed"], "batches": st["batches"],
+                       "fill_threads": args.threads, "shader_clock_mhz_last_fill": round(clk_mhz),
                        "generate_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,

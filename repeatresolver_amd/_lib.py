@@ -59,5 +59,7 @@ def load():
     lib.pwr_debug_last_job.restype = ci
     lib.pwr_debug_last_job.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci),
                                        ctypes.POINTER(ci), ctypes.POINTER(ci), ci]
+    lib.pwr_debug_fill_clock.restype = ci
+    lib.pwr_debug_fill_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     _lib = lib
     return lib

@@ -37,7 +37,7 @@ struct Hdr {                       // lives in device memory, one per context
     int status;                    // sticky error (PWR_ERR_*), 0 = fine
     int stop;                      // batch mode: set when a speculative job failed validation
     int ncommitted;                // batch mode: jobs committed in the current batch
-    int pad0;
+    int version;                   // bumped by every commit; columns carry the version that last changed them
     unsigned long long cells_computed;
     unsigned long long cells_reference;
 };
@@ -51,9 +51,10 @@ struct Tally {                     // 32 B per column slot
 struct JobMeta {                   // 64 B
     int k, L, lo, hi, W, entry, ok, nnew;
     unsigned maxS;
-    int valid;                     // batch mode: result still matches the committed state
+    int ver;                       // hdr->version when the job's inputs were gathered
     unsigned long long cells;
-    int pad[4];
+    int slot_lo, slot_hi;          // column slots at both ends of the gathered interval
+    unsigned clk, rclk;            // fill kernel duration in shader clocks / 100 MHz ticks (diagnostic)
 };
 
 struct DState {
@@ -68,6 +69,7 @@ struct DState {
     int *order0, *order1;
     int *rank;
     int *freelist;
+    unsigned *colver;              // [slotcap] version of the last commit that changed the column's tallies
     int *inscnt;                   // scratch [colcap], kept all-zero between commits
     int *newidx;                   // scratch [colcap]
 };
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     const int L = st.rowlen[k];
     const int W = st.hdr->W;
     if (L == 0) {
-        if (tid == 0) { m->k = k; m->L = 0; m->ok = 1; m->W = W; m->nnew = 0; m->cells = 0; m->valid = 1; }
+        if (tid == 0) { m->k = k; m->L = 0; m->ok = 1; m->W = W; m->nnew = 0; m->cells = 0; m->ver = st.hdr->version; }
         return;
     }
     const long long off = st.rowoff[k];
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     if (tid == 0) {
         const unsigned long long bound = (unsigned long long)mx * (unsigned long long)(L + n + 2 * B + 4096);
         m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx;
-        m->cells = 0; m->valid = 1;
+        m->cells = 0; m->ver = st.hdr->version; m->slot_lo = order[lo]; m->slot_hi = order[hi];
         m->ok = (mx <= 0xffffu && bound < (unsigned long long)PWR_INF) ? 1 : 0;
         if (!m->ok) atomicCAS(&st.hdr->status, 0, PWR_ERR_RANGE);
     }
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(NT) void k_fill(DState st, JobBufs jb)
     JobMeta *m = &jb.meta[job];
     const int L = m->L;
     if (L <= 0 || !m->ok) return;
+    const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
     const int lo = m->lo, hi = m->hi, W = m->W, B = st.B, H = st.H;
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint8_t *seq = st.seq + st.rowoff[m->k];
@@ -301,12 +304,23 @@ __global__ __launch_bounds__(NT) void k_fill(DState st, JobBufs jb)
 #pragma unroll
     for (int i = 0; i < C; ++i) accA[i] = accC[i] = 0;
     unsigned long long cells = 0;
-    int a = max(0, way[0] - H);
+    // Way[] / Seq_Bases[] of 64 DP rows live in one VGPR each (lane r = row 64*blk + r) and are read
+    // with v_readlane; the next block is fetched one block ahead, so no memory latency per row.
+    int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
+    int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
+    int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H);
 
     for (int x = 0; x < L; ++x) {
-        const int a_next = (x + 1 < L) ? max(0, way[x + 1] - H) : a;
+        if ((x & 63) == 0 && x > 0) {
+            wcur = wnxt; scur = snxt;
+            wnxt = way[min(x + 64 + lane, L - 1)];
+            snxt = seq[min(x + 64 + lane, L - 1)];
+        }
+        const int wn = ((x + 1) & 63) ? __builtin_amdgcn_readlane(wcur, (x + 1) & 63) : __builtin_amdgcn_readlane(wnxt, 0);
+        const int a_next = (x + 1 < L) ? max(0, wn - H) : a;
+        const int wx = __builtin_amdgcn_readlane(wcur, x & 63);
         const int Bx = min(B, W - a);
-        const int sx = seq[x];
+        const int sx = __builtin_amdgcn_readlane(scur, x & 63);
         // ---- stage column records: keep [a-1, a+B+NC) resident
         {
             const int need_hi = min(hi + 1, a + B + NC);
@@ -386,7 +400,7 @@ __global__ __launch_bounds__(NT) void k_fill(DState st, JobBufs jb)
         } else {
             // ---- entry column, PW:1352-1360: minimum over y in [ylow, W-1], ties -> largest y;
             // every column past the band has the value of the last band cell (PW:287)
-            int ylow = max(-1, way[x] - H) + 1;
+            int ylow = max(-1, wx - H) + 1;
             if (ylow > W - 1) ylow = W - 1;
             unsigned key = 0xffffffffu;
 #pragma unroll
@@ -428,6 +442,8 @@ __global__ __launch_bounds__(NT) void k_fill(DState st, JobBufs jb)
     }
     if (tid == 0) {
         m->cells = cells;
+        m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
+        m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
         atomicAdd(&st.hdr->cells_computed, cells);
     }
 }
@@ -454,8 +470,20 @@ __global__ __launch_bounds__(64) void k_trace(DState st, JobBufs jb)
     uint32_t win[4] = {0, 0, 0, 0};
     int gpre = -1, jbpre = 0;
     uint32_t pre[4] = {0, 0, 0, 0};
+    // Way[] of the current 64-row block in one VGPR (lane r = row 64*blk + r), next block prefetched;
+    // the new placements of a block are collected in a VGPR and stored 64 at a time.
+    int blk = x >> 6;
+    int wcur = way[min(blk * 64 + lane, L - 1)];
+    int wnxt = way[max(blk * 64 - 64 + lane, 0)];
+    int ncreg = 0;
     while (x >= 0) {
-        const int a = max(0, way[x] - H);
+        if ((x >> 6) != blk) {
+            if (blk * 64 + lane < L) newcol[blk * 64 + lane] = ncreg;   // block complete
+            blk = x >> 6;
+            wcur = wnxt;
+            wnxt = way[max(blk * 64 - 64 + lane, 0)];
+        }
+        const int a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
         const int Bx = min(B, W - a);
         if (y < a) { err = 1; break; }                       // left of the band: unreachable (PW:276)
         int j = min(y - a, Bx - 1);                          // past the band: implicit left moves
@@ -498,11 +526,12 @@ __global__ __launch_bounds__(64) void k_trace(DState st, JobBufs jb)
         }
         if (err) break;
         const int yy = a + found;
-        if (cbit) { if (lane == 0) newcol[x] = yy << 1; y = yy - 1; }             // PW:1394 (c)
-        else { if (lane == 0) newcol[x] = (yy << 1) | 1; y = yy; ++nnew; }        // PW:1404 (d)
+        if (cbit) { ncreg = (lane == (x & 63)) ? (yy << 1) : ncreg; y = yy - 1; }            // PW:1394 (c)
+        else { ncreg = (lane == (x & 63)) ? ((yy << 1) | 1) : ncreg; y = yy; ++nnew; }       // PW:1404 (d)
         --x;
         if (x >= 0 && y < 0) { err = 3; break; }
     }
+    if (!err && blk * 64 + lane < L) newcol[blk * 64 + lane] = ncreg;
     if (lane == 0) {
         m->nnew = nnew;
         if (err) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
@@ -517,7 +546,15 @@ __global__ __launch_bounds__(64) void k_trace(DState st, JobBufs jb)
 //   coverage(y) - rows ending in y, both taken with the realigned row removed.
 // ---------------------------------------------------------------------------------------------
 #define COMMIT_NT 1024
-__device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_nf)
+// symbol of the realigned row in existing column y: base+? from a mark array inside [y0,y1], blank outside
+__device__ __forceinline__ int row_symbol(const uint8_t *mk, int y, int lo, int y0, int y1)
+{
+    if (y < y0 || y > y1) return 5;
+    const int v = mk[y - lo];
+    return v ? v - 1 : 4;
+}
+
+__device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_i)
 {
     const int tid = threadIdx.x;
     Hdr *h = st.hdr;
@@ -541,16 +578,8 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     const int nnew = m->nnew;
     const int nfree = h->nfree, nslots = h->nslots;
     const int take = min(nnew, nfree);
-    if (tid == 0) *s_nf = 0;
-    // 1. take the row out (PW:1172-1220)
-    for (int y = way0 + tid; y <= wayL; y += COMMIT_NT) {
-        Tally *t = &st.tally[order[y]];
-        const int mk = mark[y - lo];
-        const int sym = mk ? mk - 1 : 4;
-#pragma unroll
-        for (int b = 0; b < 6; ++b) if (b != sym) t->w[b] -= 1;
-    }
-    if (tid == 0) st.tally[order[wayL]].endcnt -= 1;
+    const unsigned newver = (unsigned)h->version + 1u;
+    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; }                // [0] freed slots, [1] some column lost its last base
     for (int y = ny0 + tid; y <= nyL; y += COMMIT_NT) mark2[y - lo] = 0;
     __syncthreads();
     for (int x = tid; x < L; x += COMMIT_NT) {
@@ -558,7 +587,8 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         if (!(c & 1)) mark2[(c >> 1) - lo] = (uint8_t)(st.seq[off + x] + 1);
     }
     __syncthreads();
-    // 2. new columns (PW:1245-1332) and the slot of every base
+    // 1. new columns (PW:1245-1332) and the slot of every base.  The tallies of the neighbour column y
+    //    are read as the trace saw them: the row's old symbol taken out, the new one not yet put in.
     unsigned carry = 0;
     for (int base = 0; base < L; base += COMMIT_NT) {
         const int x = base + tid;
@@ -575,12 +605,15 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
                 const int slot = (idx < take) ? st.freelist[nfree - 1 - idx] : nslots + (idx - take);
                 const int bs = st.seq[off + x];
                 const Tally ty = st.tally[sloty];
-                const uint32_t al = ty.w[5] - ty.endcnt;                          // PW:1305-1314
+                const uint32_t cov = ty.w[5] - ((y >= way0 && y <= wayL) ? 1u : 0u);
+                const uint32_t ends = ty.endcnt - ((y == wayL) ? 1u : 0u);
+                const uint32_t al = cov - ends;                                    // PW:1305-1314
                 Tally nt;
 #pragma unroll
                 for (int b = 0; b < 6; ++b) nt.w[b] = ((b != bs) ? 1u : 0u) + ((b != 4) ? al : 0u);   // PW:1320-1325
                 nt.endcnt = 0; nt.pad = 0;
                 st.tally[slot] = nt;
+                st.colver[slot] = newver;
                 atomicAdd(&st.inscnt[y], 1);
                 aux[x] = slot;
             } else {
@@ -589,71 +622,148 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         }
     }
     __syncthreads();
-    // 3. put the row back in its new place (PW:1222-1243)
-    for (int y = ny0 + tid; y <= nyL; y += COMMIT_NT) {
-        Tally *t = &st.tally[order[y]];
-        const int mk = mark2[y - lo];
-        const int sym = mk ? mk - 1 : 4;
+    // 2. Columns_Downdater + Column_Updater fused (PW:1172-1243): only columns whose symbol for this
+    //    row really changes are touched (and stamped with the new version)
+    const int u0 = min(way0, ny0), u1 = max(wayL, nyL);
+    for (int y = u0 + tid; y <= u1; y += COMMIT_NT) {
+        const int so = row_symbol(mark, y, lo, way0, wayL);
+        const int sn = row_symbol(mark2, y, lo, ny0, nyL);
+        if (so != sn) {
+            const int slot = order[y];
+            Tally *t = &st.tally[slot];
+            uint32_t w4 = 0;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) if (b != sym) t->w[b] += 1;
+            for (int b = 0; b < 6; ++b) {
+                const uint32_t v = t->w[b] - ((so != 5 && b != so) ? 1u : 0u) + ((sn != 5 && b != sn) ? 1u : 0u);
+                t->w[b] = v;
+                if (b == 4) w4 = v;
+            }
+            st.colver[slot] = newver;
+            if (w4 == 0) s_i[1] = 1;
+        }
     }
     for (int x = tid; x < L; x += COMMIT_NT) st.pos[off + x] = aux[x];
     __syncthreads();
-    if (tid == 0) st.tally[aux[L - 1]].endcnt += 1;
-    __syncthreads();
-    // 4. W_Con (PW:706-763) + splice: new ordinal of every surviving / new column
-    carry = 0;
-    for (int base = 0; base < W; base += COMMIT_NT) {
-        const int y = base + tid;
-        const bool valid = y < W;
-        const int slot = valid ? order[y] : 0;
-        const bool keep = valid && st.tally[slot].w[4] != 0;
-        const unsigned ic = valid ? (unsigned)st.inscnt[y] : 0u;
-        const unsigned cnt = (keep ? 1u : 0u) + ic;
-        unsigned tot;
-        const unsigned incl = block_incl_add<COMMIT_NT>(cnt, sh, tot);
-        const int idx = (int)(carry + incl - cnt);
-        carry += tot;
-        if (valid) {
-            st.newidx[y] = idx;
-            if (keep) { norder[idx] = slot; st.rank[slot] = idx; }
-            else { const int p = atomicAdd(s_nf, 1); st.freelist[nfree - take + p] = slot; }
-            if (ic) st.inscnt[y] = 0;
-        }
+    if (tid == 0) {
+        const int oend = order[wayL], nend = aux[L - 1];
+        if (oend != nend) { st.tally[oend].endcnt -= 1; st.tally[nend].endcnt += 1; }
     }
-    __syncthreads();
-    for (int x = tid; x < L; x += COMMIT_NT) {
-        const int c = newcol[x];
-        if (c & 1) {
-            const int y = c >> 1;
-            int t = 0;
-            for (int xx = x - 1; xx >= 0 && newcol[xx] == c; --xx) ++t;    // earlier bases opened there too
-            const int keepy = st.tally[order[y]].w[4] != 0 ? 1 : 0;
-            const int p = st.newidx[y] + keepy + t;
-            norder[p] = aux[x];
-            st.rank[aux[x]] = p;
+    const bool restructure = (nnew > 0) || (s_i[1] != 0);
+    int Wnew = W;
+    if (restructure) {
+        // 3. W_Con (PW:706-763) + splice: new ordinal of every surviving / new column
+        carry = 0;
+        for (int base = 0; base < W; base += COMMIT_NT) {
+            const int y = base + tid;
+            const bool valid = y < W;
+            const int slot = valid ? order[y] : 0;
+            const bool keep = valid && st.tally[slot].w[4] != 0;
+            const unsigned ic = valid ? (unsigned)st.inscnt[y] : 0u;
+            const unsigned cnt = (keep ? 1u : 0u) + ic;
+            unsigned tot;
+            const unsigned incl = block_incl_add<COMMIT_NT>(cnt, sh, tot);
+            const int idx = (int)(carry + incl - cnt);
+            carry += tot;
+            if (valid) {
+                st.newidx[y] = idx;
+                if (keep) { norder[idx] = slot; st.rank[slot] = idx; }
+                else { const int p = atomicAdd(&s_i[0], 1); st.freelist[nfree - take + p] = slot; }
+                if (ic) st.inscnt[y] = 0;
+            }
         }
+        __syncthreads();
+        for (int x = tid; x < L; x += COMMIT_NT) {
+            const int c = newcol[x];
+            if (c & 1) {
+                const int y = c >> 1;
+                int t = 0;
+                for (int xx = x - 1; xx >= 0 && newcol[xx] == c; --xx) ++t;    // earlier bases opened there too
+                const int keepy = st.tally[order[y]].w[4] != 0 ? 1 : 0;
+                const int p = st.newidx[y] + keepy + t;
+                norder[p] = aux[x];
+                st.rank[aux[x]] = p;
+            }
+        }
+        Wnew = (int)carry;
     }
     __syncthreads();
     if (tid == 0) {
-        h->W = (int)carry;
-        h->nslots = nslots + (nnew - take);
-        h->nfree = nfree - take + *s_nf;
-        h->cur = cur ^ 1;
+        if (restructure) {
+            h->W = Wnew;
+            h->nslots = nslots + (nnew - take);
+            h->nfree = nfree - take + s_i[0];
+            h->cur = cur ^ 1;
+        }
+        h->version = (int)newver;
         h->cells_reference += m->cells;
-        h->ncommitted += 1;
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(COMMIT_NT) void k_commit(DState st, JobBufs jb, int job)
+// Is a speculatively computed job still exact?  Its DP inputs are: the tallies of the columns
+// lo..hi (row removed), their order, the row's own placement, and the distances to both MSA edges
+// where a clamp (PW:1496-1497, PW:1505) is active.  They are unchanged iff both end columns are still
+// alive and as far apart as before, no column in between carries a newer version, and the edge
+// distances that matter are the same.  On success the job's ordinals are shifted to today's numbering.
+__device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_i)
+{
+    const int tid = threadIdx.x;
+    const Hdr *h = st.hdr;
+    JobMeta *m = &jb.meta[job];
+    const int W = h->W;
+    const int *order = h->cur ? st.order1 : st.order0;
+    const int L = m->L;
+    int *way = jb.way + (size_t)job * jb.Lmax;
+    int *newcol = jb.newcol + (size_t)job * jb.Lmax;
+    if (m->ver == h->version) return true;                     // nothing committed since the gather
+    const int lo = m->lo, hi = m->hi;
+    const int lo2 = st.rank[m->slot_lo], hi2 = st.rank[m->slot_hi];
+    bool ok = lo2 >= 0 && lo2 < W && hi2 >= 0 && hi2 < W;
+    ok = ok && order[lo2] == m->slot_lo && order[hi2] == m->slot_hi && (hi2 - lo2) == (hi - lo);
+    const int d = lo2 - lo;
+    if (ok) {
+        const int way0 = way[0], wayL = way[L - 1], H = st.H, B = st.B;
+        if (d != 0 && !(way0 - H >= 1 && way0 + d - H >= 1)) ok = false;           // left clamp PW:1496
+        const int aL = max(0, wayL - H);
+        const bool far_old = aL + B <= m->W - 1, far_new = aL + d + B <= W - 1;
+        if (!(far_old && far_new) && (W - hi2) != (m->W - hi)) ok = false;         // right clamp PW:1497/1505
+    }
+    unsigned mx = 0;
+    if (ok) for (int y = lo2 + tid; y <= hi2; y += COMMIT_NT) mx = max(mx, st.colver[order[y]]);
+    mx = ~block_min_u32<COMMIT_NT>(~mx, sh);
+    if (ok && mx > (unsigned)m->ver) ok = false;
+    if (tid == 0) s_i[2] = ok ? 1 : 0;
+    __syncthreads();
+    ok = s_i[2] != 0;
+    if (ok && d != 0) {
+        for (int x = tid; x < L; x += COMMIT_NT) { way[x] += d; newcol[x] += 2 * d; }
+        __syncthreads();
+        if (tid == 0) { m->lo = lo + d; m->hi = hi + d; }
+    }
+    if (ok && tid == 0) m->W = W;
+    __syncthreads();
+    return ok;
+}
+
+// Commit the jobs of a batch in row order; stop at the first one whose inputs have changed.
+__global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs jb, int njobs)
 {
     __shared__ unsigned sh[COMMIT_NT / 64];
-    __shared__ int s_nf;
-    JobMeta *m = &jb.meta[job];
-    if (m->L <= 0 || !m->ok) return;
-    if (st.hdr->status != 0) return;
-    commit_job(st, jb, job, sh, &s_nf);
+    __shared__ int s_i[4];
+    Hdr *h = st.hdr;
+    if (threadIdx.x == 0) { h->ncommitted = 0; h->stop = 0; }
+    __syncthreads();
+    if (h->status != 0) return;
+    for (int j = 0; j < njobs; ++j) {
+        JobMeta *m = &jb.meta[j];
+        if (m->L > 0) {
+            if (!m->ok) break;                                                    // status already set
+            if (!validate_job(st, jb, j, sh, s_i)) { if (threadIdx.x == 0) h->stop = 1; break; }
+            commit_job(st, jb, j, sh, s_i);
+        }
+        if (threadIdx.x == 0) h->ncommitted = j + 1;
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -725,9 +835,10 @@ struct pwr_ctx {
     int W_ub = 0;                         // host upper bound of the device width
     int nslots_ub = 0;
     // options
-    int window = 1;
+    int window = 32;
+    double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
-    int threads = 1024;
+    int threads = 256;
     int cells_per_thread = 1;
     // stats
     pwr_stats stats{};
@@ -966,6 +1077,7 @@ static int upload(pwr_ctx *c)
     if ((rc = dmalloc(c, &st.freelist, st.slotcap))) return rc;
     if ((rc = dmalloc(c, &st.inscnt, st.colcap))) return rc;
     if ((rc = dmalloc(c, &st.newidx, st.colcap))) return rc;
+    if ((rc = dmalloc(c, &st.colver, st.slotcap))) return rc;
     if ((rc = dmalloc(c, &c->d_score, 1))) return rc;
     st.rowoff = d_rowoff; st.rowlen = d_rowlen; st.seq = d_seq;
     std::vector<int> ident(std::max(W, 1));
@@ -980,6 +1092,7 @@ static int upload(pwr_ctx *c)
     HIPC(hipMemcpy(st.order0, ident.data(), sizeof(int) * W, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(st.rank, ident.data(), sizeof(int) * W, hipMemcpyHostToDevice));
     HIPC(hipMemset(st.inscnt, 0, sizeof(int) * st.colcap));
+    HIPC(hipMemset(st.colver, 0, sizeof(unsigned) * st.slotcap));
     {
         std::vector<int> ids(T);
         for (int r = 0; r < T; ++r) ids[r] = r;
@@ -1036,6 +1149,7 @@ static int ensure_capacity(pwr_ctx *c, long long growth)
     if ((rc = regrow(c, &st.order1, ocol, ncap))) return rc;
     if ((rc = regrow(c, &st.rank, oslot, ncap))) return rc;
     if ((rc = regrow(c, &st.freelist, oslot, ncap))) return rc;
+    if ((rc = regrow(c, &st.colver, oslot, ncap))) return rc;
     if ((rc = regrow(c, &st.inscnt, 0, ncap))) return rc;
     if ((rc = regrow(c, &st.newidx, 0, ncap))) return rc;
     st.colcap = (int)ncap; st.slotcap = (int)ncap;
@@ -1063,6 +1177,12 @@ static int launch_fill(pwr_ctx *c, int njobs)
     else if (NT == 512 && C == 2) hipLaunchKernelGGL((k_fill<512, 2>), dim3(njobs), dim3(512), lds, c->stream, c->st, c->jb);
     else if (NT == 1024 && C == 2) hipLaunchKernelGGL((k_fill<1024, 2>), dim3(njobs), dim3(1024), lds, c->stream, c->st, c->jb);
     else if (NT == 256 && C == 4) hipLaunchKernelGGL((k_fill<256, 4>), dim3(njobs), dim3(256), lds, c->stream, c->st, c->jb);
+    else if (NT == 256 && C == 8) hipLaunchKernelGGL((k_fill<256, 8>), dim3(njobs), dim3(256), lds, c->stream, c->st, c->jb);
+    else if (NT == 128 && C == 8) hipLaunchKernelGGL((k_fill<128, 8>), dim3(njobs), dim3(128), lds, c->stream, c->st, c->jb);
+    else if (NT == 128 && C == 16) hipLaunchKernelGGL((k_fill<128, 16>), dim3(njobs), dim3(128), lds, c->stream, c->st, c->jb);
+    else if (NT == 64 && C == 16) hipLaunchKernelGGL((k_fill<64, 16>), dim3(njobs), dim3(64), lds, c->stream, c->st, c->jb);
+    else if (NT == 64 && C == 32) hipLaunchKernelGGL((k_fill<64, 32>), dim3(njobs), dim3(64), lds, c->stream, c->st, c->jb);
+    else if (NT == 512 && C == 4) hipLaunchKernelGGL((k_fill<512, 4>), dim3(njobs), dim3(512), lds, c->stream, c->st, c->jb);
     else return PWR_ERR_ARG;
     HIPC(hipGetLastError());
     if (c->profile) HIPC(hipEventRecord(e1, c->stream));
@@ -1091,6 +1211,12 @@ static int configure_kernels(pwr_ctx *c)
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<256, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<128, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<64, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<512, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
     done = true;
     return PWR_OK;
 }
@@ -1098,14 +1224,12 @@ static int configure_kernels(pwr_ctx *c)
 // choose threads / cells per thread so that the band fits: NT*C >= B
 static int pick_geometry(pwr_ctx *c)
 {
-    if (c->B <= 1024) { if (c->threads != 512 && c->threads != 256) c->threads = 1024; }
-    else c->threads = 1024;
-    c->cells_per_thread = 1;
-    while (c->threads * c->cells_per_thread < c->B) c->cells_per_thread *= 2;
-    if (c->threads == 512 && c->cells_per_thread < 2) c->cells_per_thread = 2;
-    if (c->threads == 256 && c->cells_per_thread < 4) c->cells_per_thread = 4;
-    if (c->threads == 256 && c->cells_per_thread > 4) { c->threads = 1024; c->cells_per_thread = c->B > 1024 ? 2 : 1; }
-    if (c->threads == 512 && c->cells_per_thread > 2) { c->threads = 1024; c->cells_per_thread = 2; }
+    const int nc = c->B <= 1024 ? 1024 : 2048;            // band cells per DP row handled by one work-group
+    int nt = c->threads;
+    if (nt != 64 && nt != 128 && nt != 256 && nt != 512 && nt != 1024) nt = 256;
+    if (nc / nt > 32) nt = nc / 32;
+    c->threads = nt;
+    c->cells_per_thread = nc / nt;
     return PWR_OK;
 }
 
@@ -1116,23 +1240,6 @@ static int ensure_device(pwr_ctx *c)
     int rc = upload(c);
     if (rc) { free_device(c); return rc; }
     return configure_kernels(c);
-}
-
-// one row, sequential: gather -> fill -> trace -> commit on the stream, no host sync
-static int enqueue_row(pwr_ctx *c, int k)
-{
-    if (c->rowlen[k] == 0) return PWR_OK;                                      // PW:1488
-    int rc = ensure_capacity(c, c->rowlen[k]);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_gather, dim3(1), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids + k);
-    if ((rc = launch_fill(c, 1))) return rc;
-    hipLaunchKernelGGL(k_trace, dim3(1), dim3(64), 0, c->stream, c->st, c->jb);
-    hipLaunchKernelGGL(k_commit, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, 0);
-    HIPC(hipGetLastError());
-    c->W_ub += c->rowlen[k];
-    c->nslots_ub += c->rowlen[k];
-    c->stats.rows_committed += 1;
-    return PWR_OK;
 }
 
 static int check_status(pwr_ctx *c)
@@ -1147,12 +1254,45 @@ static int check_status(pwr_ctx *c)
     return h.status;
 }
 
+// One speculative batch: rows k0 .. k0+n-1 are gathered from the committed state, filled and traced
+// side by side (one work-group each), then committed in row order by one work-group that stops at
+// the first row whose inputs an earlier commit of this batch has changed.  *done = rows finished.
+static int run_batch(pwr_ctx *c, int k0, int n, int *done)
+{
+    long long growth = 0;
+    int live = 0;
+    for (int k = k0; k < k0 + n; ++k) { growth += c->rowlen[k]; live += c->rowlen[k] > 0; }
+    *done = n;
+    if (live == 0) return PWR_OK;                                              // PW:1488 rows without bases
+    int rc = ensure_capacity(c, growth);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gather, dim3(n), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids + k0);
+    if ((rc = launch_fill(c, n))) return rc;
+    hipLaunchKernelGGL(k_trace, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
+    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n);
+    HIPC(hipGetLastError());
+    Hdr h;
+    if ((rc = read_hdr(c, &h))) return rc;
+    c->W_ub = h.W; c->nslots_ub = h.nslots;
+    if (h.status) return h.status;
+    if (h.ncommitted < 1) return PWR_ERR_INTERNAL;                             // the first job is always exact
+    *done = h.ncommitted;
+    c->stats.batches += 1;
+    for (int k = k0; k < k0 + n; ++k) {
+        if (c->rowlen[k] == 0) continue;
+        if (k < k0 + h.ncommitted) c->stats.rows_committed += 1; else c->stats.rows_recomputed += 1;
+    }
+    if (c->profile && c->ev_used >= 1024) rc = drain_events(c);
+    return rc;
+}
+
 extern "C" int pwr_realign_row(pwr_ctx *c, int k)
 {
     if (!c || k < 0 || k >= c->T) return PWR_ERR_ARG;
     int rc = ensure_device(c);
     if (rc) return rc;
-    if ((rc = enqueue_row(c, k))) return rc;
+    int done = 0;
+    if ((rc = run_batch(c, k, 1, &done))) return rc;
     return check_status(c);
 }
 
@@ -1161,10 +1301,17 @@ extern "C" int pwr_realign_round(pwr_ctx *c)
     if (!c) return PWR_ERR_ARG;
     int rc = ensure_device(c);
     if (rc) return rc;
-    for (int k = 0; k < c->T; ++k) {                                           // PW:1695: rows in input order
-        if ((rc = enqueue_row(c, k))) return rc;
-        if (c->profile && c->ev_used >= 2048) { if ((rc = drain_events(c))) return rc; }
+    int k = 0;                                                                 // PW:1695: rows in input order
+    double ema = c->batch_ema;
+    while (k < c->T) {
+        int n = (int)(2.0 * ema + 2.5);
+        n = std::max(1, std::min(n, std::min(c->window, c->T - k)));
+        int done = 0;
+        if ((rc = run_batch(c, k, n, &done))) return rc;
+        ema = 0.75 * ema + 0.25 * done;
+        k += done;
     }
+    c->batch_ema = ema;
     return check_status(c);
 }
 
@@ -1259,7 +1406,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "window")) { if (value < 1 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
     if (!strcmp(key, "threads")) {
-        if (c->on_device || (value != 256 && value != 512 && value != 1024)) return PWR_ERR_ARG;
+        if (c->on_device || (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)) return PWR_ERR_ARG;
         c->threads = (int)value;
         return PWR_OK;
     }
@@ -1304,5 +1451,18 @@ extern "C" int pwr_debug_last_job(pwr_ctx *c, int *L, int *entry, int *W, int *w
     const int n = std::min(cap, m.L);
     if (way && n > 0) HIPC(hipMemcpy(way, c->jb.way, sizeof(int) * n, hipMemcpyDeviceToHost));
     if (newcol && n > 0) HIPC(hipMemcpy(newcol, c->jb.newcol, sizeof(int) * n, hipMemcpyDeviceToHost));
+    return PWR_OK;
+}
+
+// shader clock the fill kernel of job 0 ran at: delta s_memtime / delta s_memrealtime (100 MHz)
+extern "C" int pwr_debug_fill_clock(pwr_ctx *c, double *mhz, double *fill_us)
+{
+    if (!c || !c->on_device) return PWR_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    HIPC(hipStreamSynchronize(c->stream));
+    JobMeta m;
+    HIPC(hipMemcpy(&m, c->jb.meta, sizeof m, hipMemcpyDeviceToHost));
+    if (mhz) *mhz = m.rclk ? 100.0 * (double)m.clk / (double)m.rclk : 0.0;
+    if (fill_us) *fill_us = (double)m.rclk / 100.0;
     return PWR_OK;
 }

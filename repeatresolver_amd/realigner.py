@@ -104,6 +104,11 @@ class PWReAligner:
         n = L.value
         return {"L": n, "entry": e.value, "W": w.value, "way": list(way[:n]), "newcol": list(nc[:n])}
 
+    def debug_fill_clock(self):
+        mhz, us = ctypes.c_double(), ctypes.c_double()
+        _check(self._lib.pwr_debug_fill_clock(self._h, ctypes.byref(mhz), ctypes.byref(us)), "pwr_debug_fill_clock")
+        return mhz.value, us.value
+
     # ---- the whole program, PW_ReAligner.c:1610-1759 ----
     def run(self, out_path, max_rounds=-1, log=None):
         """Round loop of main(): returns the list of totals printed; writes out_path after every

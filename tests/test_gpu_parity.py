@@ -69,6 +69,28 @@ def test_row_by_row_against_oracle(name, bw, rounds, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("window", [1, 3, 64])
+def test_batched_rounds_match_sequential_oracle(window, oracle):
+    """Speculative batches of any size must give the row-sequential result (commit in row order,
+    stale speculations recomputed)."""
+    from repeatresolver_amd.realigner import PWReAligner
+    for name, bw, rounds in (("toy_a_b50", 50, 3), ("lowcov_b300", 300, 3), ("deep_b200", 200, 2)):
+        rows = split_rows(golden_input(name))
+        g = PWReAligner(rows, bandwidth=bw, window=window)
+        g.trim_ends()
+        h = oracle.create(rows, bw)
+        oracle.lib.pwo_trim(h)
+        for _ in range(rounds):
+            g.realign_round()
+            oracle.lib.pwo_realign_round(h)
+            assert g.total_score() == oracle.lib.pwo_total_score(h)
+            assert g.export_rows() == oracle.export(h)
+        st = g.stats()
+        assert st["cells_reference"] == oracle.lib.pwo_cells(h)
+        oracle.lib.pwo_destroy(h)
+        g.close()
+
+
 def test_seeded_round_parity_and_invariants(oracle):
     """Fresh seeded input (not a fixture): two whole rounds through pwr_realign_round."""
     from repeatresolver_amd import datagen as dg
