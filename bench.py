@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--bandwidth", type=int, default=1000)
     ap.add_argument("--window", type=int, default=None)
     ap.add_argument("--threads", type=int, default=None)
+    ap.add_argument("--fill", type=int, default=None, help="0 = LDS-staged lock-step fill, 1 = wave-pipeline fill (default)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -90,7 +91,7 @@ def main():
     del msa
     gen_s = time.time() - t0
 
-    g = PWReAligner(rows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, threads=args.threads)
+    g = PWReAligner(rows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, threads=args.threads, fill=args.fill)
     g.trim_ends()
     score0 = g.total_score()            # first device call: uploads the MSA into HBM
     for _ in range(args.warmup):

@@ -83,6 +83,9 @@ struct JobBufs {
     uint32_t *dirs;                // [njobs][dirstride] traceback record, 2 bits per DP cell
     int *newcol;                   // [njobs][Lmax]   (ordinal << 1) | opened-a-new-column
     int *aux;                      // [njobs][Lmax]   slot of every base after the commit
+    unsigned *gbase;               // [njobs][Lmax]   G(anf(x)): per-DP-row base of the prefix sums
+    unsigned *lastM;               // [njobs][NC]     scores of the last DP row (wave-pipeline fill)
+    int layout;                    // 0: dirs indexed by band cell (y - anf(x)); 1: by (y - lo) mod NC
     int Lmax, colcap, NC;
     size_t dirstride;
 };
@@ -249,6 +252,10 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         }
         carry += tot;
         __syncthreads();
+    }
+    {
+        unsigned *gbase = jb.gbase + (size_t)job * jb.Lmax;
+        for (int x = tid; x < L; x += GATHER_NT) gbase[x] = rec[max(0, way[x] - H) - lo].z;
     }
     // 32-bit DP range: every finite score is at most (L + columns) * maxS (one step per base or
     // column, each costing at most maxS); unreachable cells are >= PWR_INF; prefix-sum offsets
@@ -528,6 +535,389 @@ __global__ __launch_bounds__(64) void k_trace(DState st, JobBufs jb)
         const int yy = a + found;
         if (cbit) { ncreg = (lane == (x & 63)) ? (yy << 1) : ncreg; y = yy - 1; }            // PW:1394 (c)
         else { ncreg = (lane == (x & 63)) ? ((yy << 1) | 1) : ncreg; y = yy; ++nnew; }       // PW:1404 (d)
+        --x;
+        if (x >= 0 && y < 0) { err = 3; break; }
+    }
+    if (!err && blk * 64 + lane < L) newcol[blk * 64 + lane] = ncreg;
+    if (lane == 0) {
+        m->nnew = nnew;
+        if (err) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// fill, wave-pipeline form.  Same recurrence and same min-plus scan as k_fill, but nothing is
+// staged through LDS rows and there is no work-group barrier per DP row:
+//   * columns are owned absolutely: macro-strip ms = 64*C consecutive columns belongs to wave
+//     ms mod NW, lane l holds C of them IN REGISTERS (records, and the previous DP row's scores);
+//     NW*64*C >= B + 64*C, so a wave never has two macro-strips inside one band;
+//   * inside a wave the scan is one DPP prefix-min; between waves the running minimum and the
+//     boundary score travel through small LDS mailboxes {value, tag = row+1} written with one
+//     64-bit store, so wave w works on row x while its right neighbour is still on an earlier row;
+//   * a wave whose macro-strip dropped out of the band on the left takes over the macro-strip NW
+//     further right; its records were fetched long before, its previous-row scores are the virtual
+//     extension G(y) + Ptot of PW:285-295.
+// Every wait is bounded; on a time-out the job is flagged and all waves leave.
+// ---------------------------------------------------------------------------------------------
+#define MB_D 32
+#define PT_D 512
+#define WP_SPIN_LIMIT (1 << 22)
+
+// wait until the 64-bit mailbox word SLOT (an lvalue in LDS) carries TAG in its upper half; bounded
+#define WP_WAIT(SLOT, TAG, VAL, OK)                                                              \
+    do {                                                                                         \
+        (OK) = false;                                                                            \
+        for (int spin_ = 0; spin_ < WP_SPIN_LIMIT; ++spin_) {                                    \
+            const unsigned long long v_ = __hip_atomic_load(&(SLOT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+            if ((unsigned)(v_ >> 32) == (unsigned)(TAG)) { (VAL) = (unsigned)v_; (OK) = true; break; } \
+            if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break; \
+            __builtin_amdgcn_s_sleep(1);                                                         \
+        }                                                                                        \
+        if (!(OK)) __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+    } while (0)
+
+template <int NW, int C>
+__global__ __launch_bounds__(NW * 64) void k_fill_wp(DState st, JobBufs jb)
+{
+    constexpr int MS = 64 * C, RS = NW * MS;
+    __shared__ unsigned long long mbP[NW][MB_D], mbM[NW][MB_D], ptb[PT_D];
+    __shared__ int prog[NW];
+    __shared__ int s_abort;
+
+    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    JobMeta *m = &jb.meta[job];
+    const int L = m->L;
+    if (L <= 0 || !m->ok) return;
+    const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = tid; i < NW * MB_D; i += NW * 64) { (&mbP[0][0])[i] = 0; (&mbM[0][0])[i] = 0; }
+    for (int i = tid; i < PT_D; i += NW * 64) ptb[i] = 0;
+    if (tid < NW) prog[tid] = 0;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();                                        // the only work-group barrier
+
+    const int lo = m->lo, hi = m->hi, W = m->W, B = st.B, H = st.H;
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const unsigned *gbase = jb.gbase + (size_t)job * jb.Lmax;
+    const uint8_t *seq = st.seq + st.rowoff[m->k];
+    const uint4 *rec = jb.rec + (size_t)job * jb.colcap;
+    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+    unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
+    const int wl = (wave + NW - 1) % NW, wr = (wave + 1) % NW;
+
+    // records of the wave's macro-strip: x = S0|S1<<16, y = S2|S3<<16, z = G, w = up cost
+    uint4 r[C], rn[C];
+    unsigned gleft = 0, gleftn = 0;
+    int ms = wave, msn = wave + NW;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int y = lo + ms * MS + lane * C + i;
+        r[i] = make_uint4(0, 0, 0, PWR_INF);
+        if (y <= hi) r[i] = rec[y - lo];
+        const int yn = lo + msn * MS + lane * C + i;
+        rn[i] = make_uint4(0, 0, 0, PWR_INF);
+        if (yn <= hi) rn[i] = rec[yn - lo];
+    }
+    { const int yq = lo + ms * MS - 1; gleft = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
+    { const int yq = lo + msn * MS - 1; gleftn = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
+
+    unsigned Mprev[C];
+    unsigned accA[C], accC[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) { Mprev[i] = 0; accA[i] = accC[i] = 0; }
+    bool ran_prev = false;
+    int cons_known = 0;
+    unsigned long long cells = 0;
+
+    int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
+    unsigned gcur = gbase[min(lane, L - 1)];
+    int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
+    unsigned gnxt = gbase[min(64 + lane, L - 1)];
+    int a_prev = 0, Bx_prev = 0;
+    unsigned gb_prev = 0;
+    bool dead = false;
+
+    for (int x = 0; x < L && !dead; ++x) {
+        if ((x & 63) == 0 && x > 0) {
+            wcur = wnxt; scur = snxt; gcur = gnxt;
+            wnxt = way[min(x + 64 + lane, L - 1)];
+            snxt = seq[min(x + 64 + lane, L - 1)];
+            gnxt = gbase[min(x + 64 + lane, L - 1)];
+        }
+        const int wx = __builtin_amdgcn_readlane(wcur, x & 63);
+        const int sx = __builtin_amdgcn_readlane(scur, x & 63);
+        const unsigned gb = (unsigned)__builtin_amdgcn_readlane((int)gcur, x & 63);
+        const int a = max(0, wx - H);
+        const int Bx = min(B, W - a);
+        const int ms_lo = (a - lo) / MS, ms_hi = (a + Bx - 1 - lo) / MS;
+        if (wave == 0) cells += (unsigned long long)Bx;
+        // ---- the macro-strip left the band for good: take over the one NW further right
+        while (ms < ms_lo) {
+            ms += NW;
+            if (ms == msn) {
+#pragma unroll
+                for (int i = 0; i < C; ++i) r[i] = rn[i];
+                gleft = gleftn;
+            } else {                                        // a jump skipped whole macro-strips (rare)
+                while (ms < ms_lo) ms += NW;
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const int y = lo + ms * MS + lane * C + i;
+                    r[i] = make_uint4(0, 0, 0, PWR_INF);
+                    if (y <= hi) r[i] = rec[y - lo];
+                }
+                const int yq = lo + ms * MS - 1;
+                gleft = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u;
+            }
+            msn = ms + NW;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const int yn = lo + msn * MS + lane * C + i;
+                rn[i] = make_uint4(0, 0, 0, PWR_INF);
+                if (yn <= hi) rn[i] = rec[yn - lo];
+            }
+            { const int yq = lo + msn * MS - 1; gleftn = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
+            ran_prev = false;
+        }
+        const bool task = ms <= ms_hi;
+        bool fcv[C], fav[C];
+#pragma unroll
+        for (int i = 0; i < C; ++i) { fcv[i] = false; fav[i] = false; }
+        if (task) {
+            const int y0 = lo + ms * MS;
+            const int yl = y0 + lane * C;
+            // ---- inputs from the left neighbour / from the row before
+            unsigned Mleft = PWR_INF;
+            int P_in = PWR_BIG;
+            bool ok = true;
+            unsigned pt_prev = 0;
+            bool have_pt = false;
+            if (x == 0) {
+                Mleft = 0;
+            } else {
+                const int yq = y0 - 1;
+                if (yq < a_prev) Mleft = PWR_INF;                                    // PW:276
+                else if (yq < a_prev + Bx_prev) WP_WAIT(mbM[wl][(x - 1) & (MB_D - 1)], x, Mleft, ok);
+                else {                                                               // PW:285-295
+                    WP_WAIT(ptb[(x - 1) & (PT_D - 1)], x, pt_prev, ok);
+                    have_pt = true;
+                    Mleft = (gleft - gb_prev) + pt_prev;
+                }
+                if (ok && !ran_prev) {
+                    if (!have_pt) WP_WAIT(ptb[(x - 1) & (PT_D - 1)], x, pt_prev, ok);
+#pragma unroll
+                    for (int i = 0; i < C; ++i) Mprev[i] = (r[i].z - gb_prev) + pt_prev;
+                }
+            }
+            if (ok && ms > ms_lo) {
+                unsigned v = 0;
+                WP_WAIT(mbP[wl][x & (MB_D - 1)], x + 1, v, ok);
+                P_in = (int)v;
+            }
+            if (!ok) { dead = true; break; }
+            // ---- candidates
+            const unsigned pm1_0 = (unsigned)__builtin_amdgcn_update_dpp((int)Mleft, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+            int tg[C], grel[C];
+            bool inb[C], lft[C];
+            int run = PWR_BIG;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const int rel = yl + i - a;
+                inb[i] = (unsigned)rel < (unsigned)Bx;
+                lft[i] = rel < 0;
+                grel[i] = (int)(r[i].z - gb);
+                const unsigned pm = Mprev[i];
+                const unsigned pm1 = i ? Mprev[i > 0 ? i - 1 : 0] : pm1_0;
+                const unsigned sy = (((sx & 2) ? r[i].y : r[i].x) >> ((sx & 1) * 16)) & 0xffffu;
+                const unsigned diag = pm1 + sy;                                      // PW:1503
+                const unsigned up = pm + r[i].w;                                     // PW:1507
+                const unsigned t = min(min(diag, up), PWR_INF);
+                fcv[i] = diag <= up;
+                tg[i] = inb[i] ? (int)t - grel[i] : PWR_BIG;
+                run = min(run, tg[i]);
+            }
+            const int incl = wave_incl_min(run);
+            const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
+            const int P_end = min(P_in, __builtin_amdgcn_readlane(incl, 63));
+            int p = min(P_in, excl);
+            unsigned Mn[C];
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                fav[i] = tg[i] >= p;
+                p = min(p, tg[i]);
+                Mn[i] = lft[i] ? PWR_INF : (unsigned)(grel[i] + p);
+            }
+            if (x == L - 1) {
+                // PW:1386: on the last row "M == M(x,y-1)" also moves left; keep the row for the entry scan
+                unsigned mrow = PWR_INF;
+                if (ms > ms_lo) { bool ok2; WP_WAIT(mbM[wl][x & (MB_D - 1)], x + 1, mrow, ok2); if (!ok2) { dead = true; break; } }
+                const unsigned left0 = (unsigned)__builtin_amdgcn_update_dpp((int)mrow, (int)Mn[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const unsigned lf = i ? Mn[i > 0 ? i - 1 : 0] : left0;
+                    fav[i] = fav[i] || (inb[i] && Mn[i] == lf);
+                    lastM[wave * MS + lane * C + i] = inb[i] ? Mn[i] : 0xffffffffu;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < C; ++i) Mprev[i] = Mn[i];
+            // ---- publish for the right neighbour (and the row minimum for late joiners)
+            const int need = x - MB_D + 2;
+            if (need > cons_known) {
+                int v = 0, spin = 0;
+                for (; spin < WP_SPIN_LIMIT; ++spin) {
+                    v = __hip_atomic_load(&prog[wr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (v >= need || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (spin == WP_SPIN_LIMIT) __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { dead = true; break; }
+                cons_known = v;
+            }
+            if (lane == 63) {
+                const unsigned long long tag = (unsigned long long)(unsigned)(x + 1) << 32;
+                __hip_atomic_store(&mbM[wave][x & (MB_D - 1)], tag | (unsigned long long)Mn[C - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&mbP[wave][x & (MB_D - 1)], tag | (unsigned long long)(unsigned)P_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (ms == ms_hi) __hip_atomic_store(&ptb[x & (PT_D - 1)], tag | (unsigned long long)(unsigned)P_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            ran_prev = true;
+        } else {
+            ran_prev = false;
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            accA[i] = (accA[i] << 1) | (fav[i] ? 1u : 0u);
+            accC[i] = (accC[i] << 1) | (fcv[i] ? 1u : 0u);
+        }
+        if ((x & 15) == 15 || x == L - 1) {
+            const int sh = 15 - (x & 15);
+            uint32_t *d = dirs + (size_t)(x >> 4) * RS + (size_t)wave * MS + (size_t)lane * C;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                d[i] = ((accA[i] << sh) & 0xffffu) | (((accC[i] << sh) & 0xffffu) << 16);
+                accA[i] = accC[i] = 0;
+            }
+        }
+        if (lane == 0) __hip_atomic_store(&prog[wave], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        a_prev = a; Bx_prev = Bx; gb_prev = gb;
+    }
+    if (dead || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        if (lane == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+        return;
+    }
+    if (tid == 0) {
+        m->cells = cells;
+        m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
+        m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
+        atomicAdd(&st.hdr->cells_computed, cells);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trace for the wave-pipeline layout (dirs indexed by (y - lo) mod RS, the same word for a column
+// in every row of a 16-row group).  Also picks the entry column (PW:1352-1360) from lastM.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
+{
+    const int job = blockIdx.x, lane = threadIdx.x;
+    JobMeta *m = &jb.meta[job];
+    const int L = m->L;
+    if (L <= 0 || !m->ok) return;
+    const int W = m->W, B = st.B, H = st.H, RS = jb.NC, lo = m->lo;
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+    const unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
+    int *newcol = jb.newcol + (size_t)job * jb.Lmax;
+
+    int x = L - 1, err = 0, nnew = 0;
+    int y;
+    {   // entry: minimum of the last row over y in [ylow, W-1], ties -> largest y; columns past the band
+        // carry the value of the last band cell (PW:287)
+        const int wx = way[x];
+        const int a = max(0, wx - H), Bx = min(B, W - a);
+        int ylow = max(-1, wx - H) + 1;
+        if (ylow > W - 1) ylow = W - 1;
+        unsigned long long key = ~0ull;
+        for (int yy = max(ylow, a) + lane; yy < a + Bx; yy += 64) {
+            const unsigned v = lastM[(yy - lo) % RS];
+            const unsigned long long k2 = ((unsigned long long)v << 32) | (unsigned)(~(unsigned)yy);
+            key = k2 < key ? k2 : key;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other < key ? other : key;
+        }
+        const unsigned vmin = (unsigned)(key >> 32);
+        int entry = (key == ~0ull) ? -1 : (int)(~(unsigned)key);
+        if (a + B <= W - 1) {
+            const unsigned lastval = lastM[(a + B - 1 - lo) % RS];
+            if (entry < 0 || lastval <= vmin) entry = W - 1;
+        }
+        y = entry;
+        if (lane == 0) m->entry = entry;
+        if (entry < 0) err = 4;
+    }
+    int gcur = -1, yb = 0;
+    uint32_t win[4] = {0, 0, 0, 0};
+    int gpre = -1, ybpre = 0;
+    uint32_t pre[4] = {0, 0, 0, 0};
+    int blk = x >> 6;
+    int wcur = way[min(blk * 64 + lane, L - 1)];
+    int wnxt = way[max(blk * 64 - 64 + lane, 0)];
+    int ncreg = 0;
+    while (x >= 0 && !err) {
+        if ((x >> 6) != blk) {
+            if (blk * 64 + lane < L) newcol[blk * 64 + lane] = ncreg;
+            blk = x >> 6;
+            wcur = wnxt;
+            wnxt = way[max(blk * 64 - 64 + lane, 0)];
+        }
+        const int a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+        const int Bx = min(B, W - a);
+        if (y < a) { err = 1; break; }
+        int yc = min(y, a + Bx - 1);                         // past the band: implicit left moves
+        const int g = x >> 4, sh = 15 - (x & 15);
+        int found = -1, cbit = 0;
+        for (;;) {
+            if (g != gcur || yc < yb || yc > yb + 255) {
+                const int want = max(lo, yc - 191);
+                if (gpre == g && ybpre == want) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) win[q] = pre[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) win[q] = dirs[(size_t)g * RS + (want + 64 * q + lane - lo) % RS];
+                }
+                gcur = g; yb = want;
+                if (g > 0) {
+                    gpre = g - 1; ybpre = want;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pre[q] = dirs[(size_t)(g - 1) * RS + (want + 64 * q + lane - lo) % RS];
+                }
+            }
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                if (found < 0) {
+                    const int cy = yb + 64 * q + lane;
+                    const bool abit = (win[q] >> sh) & 1u;
+                    const unsigned long long mk = __ballot(cy <= yc && cy >= a && !abit);
+                    if (mk) {
+                        const int t = 63 - __builtin_clzll(mk);
+                        found = yb + 64 * q + t;
+                        const unsigned long long ck = __ballot((win[q] >> (16 + sh)) & 1u);
+                        cbit = (int)((ck >> t) & 1ull);
+                    }
+                }
+            }
+            if (found >= 0) break;
+            if (yb <= a) { err = 2; break; }
+            yc = yb - 1;
+        }
+        if (err) break;
+        const int yy = found;
+        if (cbit) { ncreg = (lane == (x & 63)) ? (yy << 1) : ncreg; y = yy - 1; }              // PW:1394 (c)
+        else { ncreg = (lane == (x & 63)) ? ((yy << 1) | 1) : ncreg; y = yy; ++nnew; }         // PW:1404 (d)
         --x;
         if (x >= 0 && y < 0) { err = 3; break; }
     }
@@ -839,6 +1229,7 @@ struct pwr_ctx {
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
     int threads = 256;
+    int fill_mode = 1;                    // 0: LDS-staged lock-step fill (k_fill), 1: wave-pipeline fill (k_fill_wp)
     int cells_per_thread = 1;
     // stats
     pwr_stats stats{};
@@ -977,7 +1368,8 @@ static void host_trim(pwr_ctx *c)
 static int alloc_jobs(pwr_ctx *c, int njobs)
 {
     JobBufs &jb = c->jb;
-    const int NC = c->threads * c->cells_per_thread;
+    const int NC = c->fill_mode ? 9 * 64 * (c->B <= 1024 ? 2 : 4) : c->threads * c->cells_per_thread;
+    jb.layout = c->fill_mode ? 1 : 0;
     jb.Lmax = std::max(c->Lmax, 1);
     jb.colcap = c->st.colcap;
     jb.NC = NC;
@@ -991,6 +1383,8 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     if ((rc = dmalloc(c, &jb.dirs, (size_t)njobs * jb.dirstride))) return rc;
     if ((rc = dmalloc(c, &jb.newcol, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.aux, (size_t)njobs * jb.Lmax))) return rc;
+    if ((rc = dmalloc(c, &jb.gbase, (size_t)njobs * jb.Lmax))) return rc;
+    if ((rc = dmalloc(c, &jb.lastM, (size_t)njobs * jb.NC))) return rc;
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
     if (hipMemset(jb.meta, 0, sizeof(JobMeta) * njobs) != hipSuccess) return PWR_ERR_DEVICE;
     c->njobs = njobs;
@@ -1001,7 +1395,7 @@ static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
     dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.rec); dfree(c, jb.mark); dfree(c, jb.mark2);
-    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, c->d_jobrows);
+    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.lastM); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -1173,7 +1567,11 @@ static int launch_fill(pwr_ctx *c, int njobs)
         c->ev_used++;
         HIPC(hipEventRecord(e0, c->stream));
     }
-    if (NT == 1024 && C == 1) hipLaunchKernelGGL((k_fill<1024, 1>), dim3(njobs), dim3(1024), lds, c->stream, c->st, c->jb);
+    if (c->fill_mode) {
+        if (c->B <= 1024) hipLaunchKernelGGL((k_fill_wp<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
+        else hipLaunchKernelGGL((k_fill_wp<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
+    }
+    else if (NT == 1024 && C == 1) hipLaunchKernelGGL((k_fill<1024, 1>), dim3(njobs), dim3(1024), lds, c->stream, c->st, c->jb);
     else if (NT == 512 && C == 2) hipLaunchKernelGGL((k_fill<512, 2>), dim3(njobs), dim3(512), lds, c->stream, c->st, c->jb);
     else if (NT == 1024 && C == 2) hipLaunchKernelGGL((k_fill<1024, 2>), dim3(njobs), dim3(1024), lds, c->stream, c->st, c->jb);
     else if (NT == 256 && C == 4) hipLaunchKernelGGL((k_fill<256, 4>), dim3(njobs), dim3(256), lds, c->stream, c->st, c->jb);
@@ -1268,7 +1666,8 @@ static int run_batch(pwr_ctx *c, int k0, int n, int *done)
     if (rc) return rc;
     hipLaunchKernelGGL(k_gather, dim3(n), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids + k0);
     if ((rc = launch_fill(c, n))) return rc;
-    hipLaunchKernelGGL(k_trace, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
+    if (c->fill_mode) hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
+    else hipLaunchKernelGGL(k_trace, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
     hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n);
     HIPC(hipGetLastError());
     Hdr h;
@@ -1405,6 +1804,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!c || !key) return PWR_ERR_ARG;
     if (!strcmp(key, "window")) { if (value < 1 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
+    if (!strcmp(key, "fill")) { if (c->on_device || (value != 0 && value != 1)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "threads")) {
         if (c->on_device || (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)) return PWR_ERR_ARG;
         c->threads = (int)value;

@@ -33,12 +33,13 @@ STEP_CASES = [("toy_a_b1000", 1000, 2), ("toy_a_b50", 50, 2), ("tiny_b10", 10, 3
               ("lowcov_b300", 300, 3), ("edge_shift", 12, 2), ("deep_b200", 200, 1)]
 
 
+@pytest.mark.parametrize("fill", [1, 0], ids=["wavepipe", "ldsfill"])
 @pytest.mark.parametrize("name,bw,rounds", STEP_CASES, ids=[c[0] for c in STEP_CASES])
-def test_row_by_row_against_oracle(name, bw, rounds, oracle):
+def test_row_by_row_against_oracle(name, bw, rounds, fill, oracle):
     """Every single realignment: same Way, same entry column, same new placement, same MSA."""
     from repeatresolver_amd.realigner import PWReAligner
     rows = split_rows(golden_input(name))
-    g = PWReAligner(rows, bandwidth=bw)
+    g = PWReAligner(rows, bandwidth=bw, fill=fill)
     g.trim_ends()
     lib = oracle.lib
     h = oracle.create(rows, bw)
@@ -69,14 +70,15 @@ def test_row_by_row_against_oracle(name, bw, rounds, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("fill", [1, 0], ids=["wavepipe", "ldsfill"])
 @pytest.mark.parametrize("window", [1, 3, 64])
-def test_batched_rounds_match_sequential_oracle(window, oracle):
+def test_batched_rounds_match_sequential_oracle(window, fill, oracle):
     """Speculative batches of any size must give the row-sequential result (commit in row order,
     stale speculations recomputed)."""
     from repeatresolver_amd.realigner import PWReAligner
     for name, bw, rounds in (("toy_a_b50", 50, 3), ("lowcov_b300", 300, 3), ("deep_b200", 200, 2)):
         rows = split_rows(golden_input(name))
-        g = PWReAligner(rows, bandwidth=bw, window=window)
+        g = PWReAligner(rows, bandwidth=bw, window=window, fill=fill)
         g.trim_ends()
         h = oracle.create(rows, bw)
         oracle.lib.pwo_trim(h)
@@ -123,3 +125,18 @@ def test_seeded_round_parity_and_invariants(oracle):
     assert st["cells_reference"] == lib.pwo_cells(h)
     lib.pwo_destroy(h)
     g.close()
+
+
+def test_sections_on_gpu(oracle):
+    """configs[3] in small: Window.py-style column sections, each realigned on the GPU on its own,
+    must equal the oracle run on the same section (parity is per slice)."""
+    from repeatresolver_amd.sharding import realign_sections
+    from repeatresolver_amd.window import slice_sections
+    from test_window_sharding import _oracle_worker
+    rows = split_rows(golden_input("toy_a_b1000"))
+    W = len(rows[0])
+    secs = slice_sections(rows, [0, W // 3, 2 * W // 3, W])
+    got = realign_sections(secs, bandwidth=200, max_rounds=2)
+    for p, sec in enumerate(secs):
+        exp, _ = _oracle_worker(sec, 200, 0, 2)
+        assert got[p] == exp
