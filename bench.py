@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--bandwidth", type=int, default=1000)
     ap.add_argument("--window", type=int, default=None)
     ap.add_argument("--threads", type=int, default=None)
-    ap.add_argument("--fill", type=int, default=None, help="0 = LDS-staged lock-step fill, 1 = wave-pipeline fill (default)")
+    ap.add_argument("--fill", type=int, default=None, help="DP fill kernel: 2 lock-step wave pipeline (default), 1 polled wave pipeline, 0 LDS-staged rows")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

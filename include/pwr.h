@@ -77,7 +77,7 @@ int pwr_dims(pwr_ctx *ctx, int *rows, int *width);
 int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
 
 /* Knobs and counters (ours). keys: "window" (max rows filled speculatively per batch, >= 1),
- * "profile" (1 = time every fill launch with HIP events), "fill" (1 = wave-pipeline DP fill, the default; 0 = LDS-staged lock-step fill), "threads" (work-group size of the DP fill: 64, 128, 256, 512 or 1024). */
+ * "profile" (1 = time every fill launch with HIP events), "fill" (DP fill kernel: 2 = wave pipeline in lock-step rounds, the default; 1 = wave pipeline with polled mailboxes; 0 = LDS-staged rows), "threads" (work-group size of the DP fill: 64, 128, 256, 512 or 1024). */
 int pwr_set_option(pwr_ctx *ctx, const char *key, long value);
 int pwr_get_stats(pwr_ctx *ctx, pwr_stats *out);
 int pwr_reset_stats(pwr_ctx *ctx);

@@ -253,10 +253,19 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         carry += tot;
         __syncthreads();
     }
+    unsigned long long mycells = 0;
     {
         unsigned *gbase = jb.gbase + (size_t)job * jb.Lmax;
-        for (int x = tid; x < L; x += GATHER_NT) gbase[x] = rec[max(0, way[x] - H) - lo].z;
+        for (int x = tid; x < L; x += GATHER_NT) {
+            const int ax = max(0, way[x] - H);
+            gbase[x] = rec[ax - lo].z;
+            mycells += (unsigned long long)min(B, W - ax);                  // cells of DP row x, PW:1496-1499
+        }
     }
+    for (int o = 32; o > 0; o >>= 1) mycells += __shfl_xor(mycells, o);
+    __shared__ unsigned long long s_cells[GATHER_NT / 64];
+    if ((tid & 63) == 0) s_cells[tid >> 6] = mycells;
+    __syncthreads();
     // 32-bit DP range: every finite score is at most (L + columns) * maxS (one step per base or
     // column, each costing at most maxS); unreachable cells are >= PWR_INF; prefix-sum offsets
     // inside one DP row add at most (B + lookahead) * maxS.
@@ -264,7 +273,9 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     if (tid == 0) {
         const unsigned long long bound = (unsigned long long)mx * (unsigned long long)(L + n + 2 * B + 4096);
         m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx;
-        m->cells = 0; m->ver = st.hdr->version; m->slot_lo = order[lo]; m->slot_hi = order[hi];
+        unsigned long long cs = 0;
+        for (int w = 0; w < GATHER_NT / 64; ++w) cs += s_cells[w];
+        m->cells = cs; m->ver = st.hdr->version; m->slot_lo = order[lo]; m->slot_hi = order[hi];
         m->ok = (mx <= 0xffffu && bound < (unsigned long long)PWR_INF) ? 1 : 0;
         if (!m->ok) atomicCAS(&st.hdr->status, 0, PWR_ERR_RANGE);
     }
@@ -448,10 +459,10 @@ __global__ __launch_bounds__(NT) void k_fill(DState st, JobBufs jb)
         a = a_next;
     }
     if (tid == 0) {
-        m->cells = cells;
         m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
         m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
-        atomicAdd(&st.hdr->cells_computed, cells);
+        atomicAdd(&st.hdr->cells_computed, m->cells);
+        (void)cells;
     }
 }
 
@@ -807,10 +818,274 @@ __global__ __launch_bounds__(NW * 64) void k_fill_wp(DState st, JobBufs jb)
         return;
     }
     if (tid == 0) {
-        m->cells = cells;
         m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
         m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
-        atomicAdd(&st.hdr->cells_computed, cells);
+        atomicAdd(&st.hdr->cells_computed, m->cells);
+        (void)cells;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// fill, lock-step round form of the wave pipeline.  Same ownership as k_fill_wp (macro-strip ms of
+// 64*C columns -> wave ms mod NW, records and previous-row scores in registers, DPP scan inside the
+// wave) but the waves advance in rounds separated by ONE s_barrier: in a round every wave whose
+// inputs for its next DP row are present (left neighbour's running minimum / boundary score of
+// that row, tagged with the row number) computes that row and posts its own outputs; what it reads
+// was written before the last barrier, so there is no polling and no spin.  In steady state wave w
+// is one row behind wave w-1 and the work-group retires one DP row per round.
+// ---------------------------------------------------------------------------------------------
+#define LS_D 16
+#define LS_PD 64
+template <int NW, int C>
+__global__ __launch_bounds__(NW * 64) void k_fill_ls(DState st, JobBufs jb)
+{
+    constexpr int MS = 64 * C, RS = NW * MS;
+    __shared__ uint4 mb[NW][LS_D];                  // {P_end, M_last, tag = row + 1, -}
+    __shared__ uint2 ptb[LS_PD];                    // {Ptot, tag}
+    __shared__ int s_done;
+
+    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    JobMeta *m = &jb.meta[job];
+    const int L = m->L;
+    if (L <= 0 || !m->ok) return;
+    const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = tid; i < NW * LS_D; i += NW * 64) (&mb[0][0])[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < LS_PD; i += NW * 64) ptb[i] = make_uint2(0, 0);
+    if (tid == 0) s_done = 0;
+    __syncthreads();
+
+    const int lo = m->lo, hi = m->hi, W = m->W, B = st.B, H = st.H;
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const unsigned *gbase = jb.gbase + (size_t)job * jb.Lmax;
+    const uint8_t *seq = st.seq + st.rowoff[m->k];
+    const uint4 *rec = jb.rec + (size_t)job * jb.colcap;
+    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+    unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
+    const int wl = (wave + NW - 1) % NW;
+    const int lc = lane * C;
+
+    unsigned rx[C], ry[C], rz[C], rw[C], nx[C], ny[C], nz[C], nw[C];     // records (current / prefetched macro-strip)
+    unsigned gleft = 0, gleftn = 0;
+    int ms = wave, msn = wave + NW;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        const int y = lo + ms * MS + lc + i;
+        uint4 t4 = make_uint4(0, 0, 0, PWR_INF);
+        if (y <= hi) t4 = rec[y - lo];
+        rx[i] = t4.x; ry[i] = t4.y; rz[i] = t4.z; rw[i] = t4.w;
+        const int yn = lo + msn * MS + lc + i;
+        uint4 u4 = make_uint4(0, 0, 0, PWR_INF);
+        if (yn <= hi) u4 = rec[yn - lo];
+        nx[i] = u4.x; ny[i] = u4.y; nz[i] = u4.z; nw[i] = u4.w;
+    }
+    { const int yq = lo + ms * MS - 1; gleft = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
+    { const int yq = lo + msn * MS - 1; gleftn = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
+
+    unsigned Mprev[C], accA[C], accC[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) { Mprev[i] = 0; accA[i] = accC[i] = 0; }
+    bool ran_prev = false, finished = false;
+    int x = 0;                                              // this wave's next DP row
+    int blk = 0;
+    int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
+    unsigned gcur = gbase[min(lane, L - 1)];
+    int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
+    unsigned gnxt = gbase[min(64 + lane, L - 1)];
+    // row parameters of row x and of row x-1 (kept in SGPRs)
+    int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H), a_prev = 0, Bx_prev = 0;
+    unsigned gb = (unsigned)__builtin_amdgcn_readlane((int)gcur, 0), gb_prev = 0;
+    int sx = __builtin_amdgcn_readlane(scur, 0);
+    const int max_rounds = 4 * L + 64 * NW + 1024;
+    int round = 0;
+
+    for (; round < max_rounds; ++round) {
+        if (!finished) {
+            int Bx = min(B, W - a);
+            int ms_lo = (a - lo) / MS, ms_hi = (a + Bx - 1 - lo) / MS;
+            // rows in which this wave's macro-strip is not inside the band cost nothing: skip them
+            // (taking over the macro-strip NW further right when the current one is left behind)
+            for (;;) {
+                if (ms < ms_lo) {
+                    ms += NW;
+                    if (ms == msn) {
+#pragma unroll
+                        for (int i = 0; i < C; ++i) { rx[i] = nx[i]; ry[i] = ny[i]; rz[i] = nz[i]; rw[i] = nw[i]; }
+                        gleft = gleftn;
+                    } else {
+                        while (ms < ms_lo) ms += NW;
+#pragma unroll
+                        for (int i = 0; i < C; ++i) {
+                            const int y = lo + ms * MS + lc + i;
+                            uint4 t4 = make_uint4(0, 0, 0, PWR_INF);
+                            if (y <= hi) t4 = rec[y - lo];
+                            rx[i] = t4.x; ry[i] = t4.y; rz[i] = t4.z; rw[i] = t4.w;
+                        }
+                        const int yq = lo + ms * MS - 1;
+                        gleft = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u;
+                    }
+                    msn = ms + NW;
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        const int yn = lo + msn * MS + lc + i;
+                        uint4 u4 = make_uint4(0, 0, 0, PWR_INF);
+                        if (yn <= hi) u4 = rec[yn - lo];
+                        nx[i] = u4.x; ny[i] = u4.y; nz[i] = u4.z; nw[i] = u4.w;
+                    }
+                    { const int yq = lo + msn * MS - 1; gleftn = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
+                    ran_prev = false;
+                    continue;
+                }
+                if (ms <= ms_hi) break;                     // a task
+                // no task in row x: keep the traceback words aligned and move on
+#pragma unroll
+                for (int i = 0; i < C; ++i) { accA[i] <<= 1; accC[i] <<= 1; }
+                if ((x & 15) == 15 || x == L - 1) {
+                    const int sh = 15 - (x & 15);
+                    uint32_t *d = dirs + (size_t)(x >> 4) * RS + (size_t)wave * MS + (size_t)lc;
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        d[i] = ((accA[i] << sh) & 0xffffu) | (((accC[i] << sh) & 0xffffu) << 16);
+                        accA[i] = accC[i] = 0;
+                    }
+                }
+                ran_prev = false;
+                a_prev = a; Bx_prev = Bx; gb_prev = gb;
+                ++x;
+                if (x == L) { finished = true; break; }
+                if ((x >> 6) != blk) {
+                    blk = x >> 6;
+                    wcur = wnxt; scur = snxt; gcur = gnxt;
+                    wnxt = way[min(x + 64 + lane, L - 1)];
+                    snxt = seq[min(x + 64 + lane, L - 1)];
+                    gnxt = gbase[min(x + 64 + lane, L - 1)];
+                }
+                a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+                gb = (unsigned)__builtin_amdgcn_readlane((int)gcur, x & 63);
+                sx = __builtin_amdgcn_readlane(scur, x & 63);
+                Bx = min(B, W - a);
+                ms_lo = (a - lo) / MS; ms_hi = (a + Bx - 1 - lo) / MS;
+            }
+            if (finished) {
+                if (lane == 0) atomicAdd(&s_done, 1);
+            } else {
+                // ---- are the inputs of (x, ms) there?  (everything read here was written before the last barrier)
+                const int y0 = lo + ms * MS;
+                const int yq = y0 - 1;
+                const bool needP = ms > ms_lo;
+                const bool needM = x > 0 && yq >= a_prev && yq < a_prev + Bx_prev;          // boundary score of row x-1
+                const bool needT = x > 0 && ((yq >= a_prev + Bx_prev) || !ran_prev);        // row minimum of row x-1
+                const uint4 eP = mb[wl][x & (LS_D - 1)];
+                const uint4 eM = mb[wl][(x - 1) & (LS_D - 1)];
+                const uint2 eT = ptb[(x - 1) & (LS_PD - 1)];
+                const bool ready = (!needP || eP.z == (unsigned)(x + 1)) && (!needM || eM.z == (unsigned)x) &&
+                                   (!needT || eT.y == (unsigned)x);
+                if (ready) {
+                    unsigned Mleft = PWR_INF;
+                    if (x == 0) Mleft = 0;
+                    else if (yq < a_prev) Mleft = PWR_INF;                                   // PW:276
+                    else if (needM) Mleft = eM.y;
+                    else Mleft = (gleft - gb_prev) + eT.x;                                   // PW:285-295
+                    const int P_in = needP ? (int)eP.x : PWR_BIG;
+                    if (x > 0 && !ran_prev) {
+#pragma unroll
+                        for (int i = 0; i < C; ++i) Mprev[i] = (rz[i] - gb_prev) + eT.x;
+                    }
+                    const unsigned pm1_0 = (unsigned)__builtin_amdgcn_update_dpp((int)Mleft, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+                    int tg[C], grel[C];
+                    bool inb[C], lft[C], fcv[C], fav[C];
+                    int run = PWR_BIG;
+                    const int rel0 = y0 + lc - a;
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        const int rel = rel0 + i;
+                        inb[i] = (unsigned)rel < (unsigned)Bx;
+                        lft[i] = rel < 0;
+                        grel[i] = (int)(rz[i] - gb);
+                        const unsigned pm = Mprev[i];
+                        const unsigned pm1 = i ? Mprev[i > 0 ? i - 1 : 0] : pm1_0;
+                        const unsigned sy = (((sx & 2) ? ry[i] : rx[i]) >> ((sx & 1) * 16)) & 0xffffu;
+                        const unsigned diag = pm1 + sy;                                      // PW:1503
+                        const unsigned up = pm + rw[i];                                     // PW:1507
+                        const unsigned t = min(min(diag, up), PWR_INF);
+                        fcv[i] = diag <= up;
+                        tg[i] = inb[i] ? (int)t - grel[i] : PWR_BIG;
+                        run = min(run, tg[i]);
+                    }
+                    const int incl = wave_incl_min(run);
+                    const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
+                    const int P_end = min(P_in, __builtin_amdgcn_readlane(incl, 63));
+                    int p = min(P_in, excl);
+                    unsigned Mn[C];
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        fav[i] = tg[i] >= p;
+                        p = min(p, tg[i]);
+                        Mn[i] = lft[i] ? PWR_INF : (unsigned)(grel[i] + p);
+                    }
+                    if (x == L - 1) {
+                        // PW:1386: on the last row "M == M(x,y-1)" also moves left; keep the row for the entry scan
+                        const unsigned mrow = needP ? eP.y : PWR_INF;
+                        const unsigned left0 = (unsigned)__builtin_amdgcn_update_dpp((int)mrow, (int)Mn[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+#pragma unroll
+                        for (int i = 0; i < C; ++i) {
+                            const unsigned lf = i ? Mn[i > 0 ? i - 1 : 0] : left0;
+                            fav[i] = fav[i] || (inb[i] && Mn[i] == lf);
+                            lastM[wave * MS + lc + i] = inb[i] ? Mn[i] : 0xffffffffu;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        Mprev[i] = Mn[i];
+                        accA[i] = (accA[i] << 1) | (fav[i] ? 1u : 0u);
+                        accC[i] = (accC[i] << 1) | (fcv[i] ? 1u : 0u);
+                    }
+                    if (lane == 63) {
+                        mb[wave][x & (LS_D - 1)] = make_uint4((unsigned)P_end, Mn[C - 1], (unsigned)(x + 1), 0u);
+                        if (ms == ms_hi) ptb[x & (LS_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)(x + 1));
+                    }
+                    if ((x & 15) == 15 || x == L - 1) {
+                        const int sh = 15 - (x & 15);
+                        uint32_t *d = dirs + (size_t)(x >> 4) * RS + (size_t)wave * MS + (size_t)lc;
+#pragma unroll
+                        for (int i = 0; i < C; ++i) {
+                            d[i] = ((accA[i] << sh) & 0xffffu) | (((accC[i] << sh) & 0xffffu) << 16);
+                            accA[i] = accC[i] = 0;
+                        }
+                    }
+                    ran_prev = true;
+                    a_prev = a; Bx_prev = Bx; gb_prev = gb;
+                    ++x;
+                    if (x == L) {
+                        finished = true;
+                        if (lane == 0) atomicAdd(&s_done, 1);
+                    } else {
+                        if ((x >> 6) != blk) {
+                            blk = x >> 6;
+                            wcur = wnxt; scur = snxt; gcur = gnxt;
+                            wnxt = way[min(x + 64 + lane, L - 1)];
+                            snxt = seq[min(x + 64 + lane, L - 1)];
+                            gnxt = gbase[min(x + 64 + lane, L - 1)];
+                        }
+                        a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+                        gb = (unsigned)__builtin_amdgcn_readlane((int)gcur, x & 63);
+                        sx = __builtin_amdgcn_readlane(scur, x & 63);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= NW) break;
+    }
+    if (round >= max_rounds) {
+        if (tid == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+        return;
+    }
+    if (tid == 0) {
+        m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
+        m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
+        atomicAdd(&st.hdr->cells_computed, m->cells);
     }
 }
 
@@ -1229,7 +1504,7 @@ struct pwr_ctx {
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
     int threads = 256;
-    int fill_mode = 1;                    // 0: LDS-staged lock-step fill (k_fill), 1: wave-pipeline fill (k_fill_wp)
+    int fill_mode = 2;                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 2: wave pipeline in lock-step rounds (k_fill_ls)
     int cells_per_thread = 1;
     // stats
     pwr_stats stats{};
@@ -1567,7 +1842,10 @@ static int launch_fill(pwr_ctx *c, int njobs)
         c->ev_used++;
         HIPC(hipEventRecord(e0, c->stream));
     }
-    if (c->fill_mode) {
+    if (c->fill_mode == 2) {
+        if (c->B <= 1024) hipLaunchKernelGGL((k_fill_ls<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
+        else hipLaunchKernelGGL((k_fill_ls<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
+    } else if (c->fill_mode == 1) {
         if (c->B <= 1024) hipLaunchKernelGGL((k_fill_wp<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_wp<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
     }
@@ -1804,7 +2082,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!c || !key) return PWR_ERR_ARG;
     if (!strcmp(key, "window")) { if (value < 1 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
-    if (!strcmp(key, "fill")) { if (c->on_device || (value != 0 && value != 1)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
+    if (!strcmp(key, "fill")) { if (c->on_device || value < 0 || value > 2) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "threads")) {
         if (c->on_device || (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)) return PWR_ERR_ARG;
         c->threads = (int)value;
