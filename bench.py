@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--window", type=int, default=None)
     ap.add_argument("--threads", type=int, default=None)
     ap.add_argument("--fill", type=int, default=None, help="DP fill kernel: 2 lock-step wave pipeline (default), 1 polled wave pipeline, 0 LDS-staged rows")
+    ap.add_argument("--waves", type=int, default=None, help="waves per DP of the v2 fill (9 or 5)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -91,7 +92,7 @@ def main():
     del msa
     gen_s = time.time() - t0
 
-    g = PWReAligner(rows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, threads=args.threads, fill=args.fill)
+    g = PWReAligner(rows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, threads=args.threads, fill=args.fill, waves=args.waves)
     g.trim_ends()
     score0 = g.total_score()            # first device call: uploads the MSA into HBM
     for _ in range(args.warmup):
@@ -110,7 +111,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     st = g.stats()
-    clk_mhz, _ = g.debug_fill_clock()
+    clk_mhz, fill_us = g.debug_fill_clock()
+    dbg = g.debug_last_job(cap=4)
+    print("debug: last job L=%d fill_us=%.1f clk=%.0f MHz rounds=%d" % (dbg["L"], fill_us, clk_mhz, dbg.get("rounds", -1)), file=sys.stderr)
     score1 = g.total_score()
     _, W1 = g.dims()
 

@@ -55,6 +55,7 @@ struct JobMeta {                   // 64 B
     unsigned long long cells;
     int slot_lo, slot_hi;          // column slots at both ends of the gathered interval
     unsigned clk, rclk;            // fill kernel duration in shader clocks / 100 MHz ticks (diagnostic)
+    int rounds, pad1;              // lock-step rounds the fill needed (diagnostic)
 };
 
 struct DState {
@@ -78,6 +79,7 @@ struct JobBufs {
     JobMeta *meta;
     int *way;                      // [njobs][Lmax]   ordinal of every base (PW:31 Way)
     uint4 *rec;                    // [njobs][colcap] DP input records of the job's column interval
+    int4 *rec2;                    // [njobs][2*colcap] the same pre-combined for k_fill_v2: {S0-G,S1-G,S2-G,S3-G},{up-G,G,INF-G,0}
     uint8_t *mark;                 // [njobs][colcap] old symbol marks (base+1 / 0)
     uint8_t *mark2;                // [njobs][colcap] new symbol marks
     uint32_t *dirs;                // [njobs][dirstride] traceback record, 2 bits per DP cell
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     const int n = hi - lo + 1;
     uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
     uint4 *rec = jb.rec + (size_t)job * jb.colcap;
+    int4 *rec2 = jb.rec2 + (size_t)job * jb.colcap * 2;
     for (int i = tid; i < n; i += GATHER_NT) mark[i] = 0;
     __syncthreads();
     for (int x = tid; x < L; x += GATHER_NT) mark[way[x] - lo] = (uint8_t)(st.seq[off + x] + 1);
@@ -248,6 +251,9 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         if (valid) {
             const unsigned upc = (y == 0 || y == W - 1) ? PWR_INF : max(w[5], covl);
             rec[i] = make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), carry + gin, upc);
+            const int g = (int)(carry + gin);
+            rec2[2 * i] = make_int4((int)w[0] - g, (int)w[1] - g, (int)w[2] - g, (int)w[3] - g);
+            rec2[2 * i + 1] = make_int4((int)(upc == PWR_INF ? PWR_INF - 1u : upc) - g, g, (int)PWR_INF - g, 0);   // INF-1: pm + up stays below 2^31
             maxS = max(maxS, max(max(w[0], w[1]), max(max(w[2], w[3]), max(w[4], w[5]))));
         }
         carry += tot;
@@ -276,7 +282,8 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         unsigned long long cs = 0;
         for (int w = 0; w < GATHER_NT / 64; ++w) cs += s_cells[w];
         m->cells = cs; m->ver = st.hdr->version; m->slot_lo = order[lo]; m->slot_hi = order[hi];
-        m->ok = (mx <= 0xffffu && bound < (unsigned long long)PWR_INF) ? 1 : 0;
+        // k_fill_v2 works with absolute prefix sums G: their total (= bases in the interval) must stay below 2^29
+        m->ok = (mx <= 0xffffu && bound < (unsigned long long)PWR_INF && carry < (1u << 29)) ? 1 : 0;
         if (!m->ok) atomicCAS(&st.hdr->status, 0, PWR_ERR_RANGE);
     }
 }
@@ -581,8 +588,10 @@ __global__ __launch_bounds__(64) void k_trace(DState st, JobBufs jb)
         (OK) = false;                                                                            \
         for (int spin_ = 0; spin_ < WP_SPIN_LIMIT; ++spin_) {                                    \
             const unsigned long long v_ = __hip_atomic_load(&(SLOT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-            if ((unsigned)(v_ >> 32) == (unsigned)(TAG)) { (VAL) = (unsigned)v_; (OK) = true; break; } \
-            if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break; \
+            const unsigned vhi_ = __builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32));              \
+            const unsigned vlo_ = __builtin_amdgcn_readfirstlane((unsigned)v_);                      \
+            if (vhi_ == (unsigned)(TAG)) { (VAL) = vlo_; (OK) = true; break; }                       \
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break; \
             __builtin_amdgcn_s_sleep(1);                                                         \
         }                                                                                        \
         if (!(OK)) __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
@@ -778,12 +787,12 @@ __global__ __launch_bounds__(NW * 64) void k_fill_wp(DState st, JobBufs jb)
             if (need > cons_known) {
                 int v = 0, spin = 0;
                 for (; spin < WP_SPIN_LIMIT; ++spin) {
-                    v = __hip_atomic_load(&prog[wr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (v >= need || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&prog[wr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (v >= need || __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (spin == WP_SPIN_LIMIT) __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { dead = true; break; }
+                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) { dead = true; break; }
                 cons_known = v;
             }
             if (lane == 63) {
@@ -976,9 +985,12 @@ __global__ __launch_bounds__(NW * 64) void k_fill_ls(DState st, JobBufs jb)
                 const bool needP = ms > ms_lo;
                 const bool needM = x > 0 && yq >= a_prev && yq < a_prev + Bx_prev;          // boundary score of row x-1
                 const bool needT = x > 0 && ((yq >= a_prev + Bx_prev) || !ran_prev);        // row minimum of row x-1
-                const uint4 eP = mb[wl][x & (LS_D - 1)];
-                const uint4 eM = mb[wl][(x - 1) & (LS_D - 1)];
-                const uint2 eT = ptb[(x - 1) & (LS_PD - 1)];
+                uint4 eP = mb[wl][x & (LS_D - 1)];
+                uint4 eM = mb[wl][(x - 1) & (LS_D - 1)];
+                uint2 eT = ptb[(x - 1) & (LS_PD - 1)];
+                eP.x = __builtin_amdgcn_readfirstlane(eP.x); eP.y = __builtin_amdgcn_readfirstlane(eP.y); eP.z = __builtin_amdgcn_readfirstlane(eP.z);
+                eM.y = __builtin_amdgcn_readfirstlane(eM.y); eM.z = __builtin_amdgcn_readfirstlane(eM.z);
+                eT.x = __builtin_amdgcn_readfirstlane(eT.x); eT.y = __builtin_amdgcn_readfirstlane(eT.y);
                 const bool ready = (!needP || eP.z == (unsigned)(x + 1)) && (!needM || eM.z == (unsigned)x) &&
                                    (!needT || eT.y == (unsigned)x);
                 if (ready) {
@@ -1076,7 +1088,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_ls(DState st, JobBufs jb)
             }
         }
         __syncthreads();
-        if (__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= NW) break;
+        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= NW) break;
     }
     if (round >= max_rounds) {
         if (tid == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
@@ -1085,6 +1097,253 @@ __global__ __launch_bounds__(NW * 64) void k_fill_ls(DState st, JobBufs jb)
     if (tid == 0) {
         m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
         m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
+        m->rounds = round;
+        atomicAdd(&st.hdr->cells_computed, m->cells);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// fill v2: the lock-step wave pipeline of k_fill_ls with the per-cell and per-row work cut down.
+//   * prefix sums G are absolute (their total is the number of bases in the interval, < 2^29, checked by
+//     the gather), so the per-column constants S_b - G, up - G, INF - G are precomputed once per column
+//     and a candidate is  tg = min3(pm1 + (S_b - G), pm + (up - G), INF - G)  -- three VALU ops;
+//   * the row's base selects one of four straight-line copies of the cell loop (no per-cell select);
+//   * traceback bits are OR-ed in at their final position; rows without work for a wave cost no VALU;
+//   * a wave may retire up to V2_R rows per round (its left neighbour is that far ahead), so the
+//     barrier is amortised; all control state is kept wave-uniform (SGPRs, scalar branches).
+// ---------------------------------------------------------------------------------------------
+#define V2_D 32
+#define V2_PD 64
+#define V2_R 8
+#define UNI(v) __builtin_amdgcn_readfirstlane(v)
+
+#define V2_CASE(SGARR)                                                                           \
+    _Pragma("unroll") for (int i = 0; i < C; ++i) {                                              \
+        const int pm1 = i ? (int)Mprev[i > 0 ? i - 1 : 0] : pm1_0;                               \
+        const int d = pm1 + SGARR[i];                                                            \
+        const int u = (int)Mprev[i] + ug[i];                                                     \
+        accC[i] |= (d <= u) ? bit : 0u;                                                          \
+        t3[i] = min(min(d, u), ig[i]);                                                           \
+    }
+
+#define V2_LOAD(MSX, A0, A1, A2, A3, AU, AG, AI, GL)                                             \
+    {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < C; ++i) {                                          \
+            const int y_ = lo + (MSX) * MS + lc + i;                                             \
+            int4 p_ = make_int4(PWR_BIG / 2, PWR_BIG / 2, PWR_BIG / 2, PWR_BIG / 2);             \
+            int4 q_ = make_int4(PWR_BIG / 2, 0, PWR_BIG / 2, 0);                                 \
+            if (y_ <= hi) { p_ = rec2[2 * (y_ - lo)]; q_ = rec2[2 * (y_ - lo) + 1]; }            \
+            A0[i] = p_.x; A1[i] = p_.y; A2[i] = p_.z; A3[i] = p_.w;                              \
+            AU[i] = q_.x; AG[i] = q_.y; AI[i] = q_.z;                                            \
+        }                                                                                        \
+        const int yq_ = lo + (MSX) * MS - 1;                                                     \
+        GL = (yq_ >= lo && yq_ <= hi) ? UNI(rec2[2 * (yq_ - lo) + 1].y) : 0;                     \
+    }
+
+template <int NW, int C>
+__global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
+{
+    constexpr int MS = 64 * C, RS = NW * MS;
+    __shared__ uint4 mb[NW][V2_D];                  // {P_end, M_last, tag = row + 1, -}
+    __shared__ uint2 ptb[V2_PD];                    // {Ptot, tag}
+    __shared__ int s_done;
+
+    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = UNI(tid >> 6);
+    JobMeta *m = &jb.meta[job];
+    const int L = UNI(m->L);
+    if (L <= 0 || !m->ok) return;
+    const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = tid; i < NW * V2_D; i += NW * 64) (&mb[0][0])[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < V2_PD; i += NW * 64) ptb[i] = make_uint2(0, 0);
+    if (tid == 0) s_done = 0;
+    __syncthreads();
+
+    const int lo = UNI(m->lo), hi = UNI(m->hi), W = UNI(m->W), B = st.B, H = st.H;
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const uint8_t *seq = st.seq + st.rowoff[UNI(m->k)];
+    const int4 *rec2 = jb.rec2 + (size_t)job * jb.colcap * 2;
+    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+    unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
+    const int wl = (wave + NW - 1) % NW;
+    const int lc = lane * C;
+
+    // per-column constants of the current (sg*, ug, gg, ig) and the prefetched (n*) macro-strip
+    int sg0[C], sg1[C], sg2[C], sg3[C], ug[C], gg[C], ig[C];
+    int n0[C], n1[C], n2[C], n3[C], nu[C], ng[C], ni[C];
+    int gleft = 0, gleftn = 0;
+    int ms = wave, msn = wave + NW;
+    V2_LOAD(ms, sg0, sg1, sg2, sg3, ug, gg, ig, gleft)
+    V2_LOAD(msn, n0, n1, n2, n3, nu, ng, ni, gleftn)
+
+    unsigned Mprev[C], accA[C], accC[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) { Mprev[i] = 0; accA[i] = accC[i] = 0; }
+    int gacc = -1;                                          // 16-row group the accumulators belong to
+    int ran_prev = 0, finished = 0;
+    int x = 0, blk = 0;
+    int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
+    int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
+    int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H), a_prev = 0, Bx_prev = 0;
+    int sx = __builtin_amdgcn_readlane(scur, 0);
+    const int max_rounds = 4 * L + 64 * NW + 1024;
+    int round = 0;
+
+#define V2_FLUSH()                                                                               \
+    if (gacc >= 0) {                                                                             \
+        uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;                \
+        _Pragma("unroll") for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; } \
+        gacc = -1;                                                                               \
+    }
+#define V2_NEXT_ROW()                                                                            \
+    {                                                                                            \
+        a_prev = a; Bx_prev = Bx;                                                                \
+        ++x;                                                                                     \
+        if (x < L) {                                                                             \
+            if ((x >> 6) != blk) {                                                               \
+                blk = x >> 6;                                                                    \
+                wcur = wnxt; scur = snxt;                                                        \
+                wnxt = way[min(x + 64 + lane, L - 1)];                                           \
+                snxt = seq[min(x + 64 + lane, L - 1)];                                           \
+            }                                                                                    \
+            a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);                             \
+            sx = __builtin_amdgcn_readlane(scur, x & 63);                                        \
+        } else {                                                                                 \
+            finished = 1;                                                                        \
+            V2_FLUSH()                                                                           \
+            if (lane == 0) atomicAdd(&s_done, 1);                                                \
+        }                                                                                        \
+    }
+
+    for (; round < max_rounds; ++round) {
+        int budget = V2_R;
+        while (budget > 0) {
+            // loop-carried control state is wave-uniform; say so, so it lives in SGPRs and branches are scalar
+            finished = UNI(finished);
+            if (finished) break;
+            x = UNI(x); ms = UNI(ms); msn = UNI(msn); a = UNI(a); a_prev = UNI(a_prev); Bx_prev = UNI(Bx_prev);
+            sx = UNI(sx); gacc = UNI(gacc); blk = UNI(blk); gleft = UNI(gleft); gleftn = UNI(gleftn); ran_prev = UNI(ran_prev);
+            const int Bx = min(B, W - a);
+            const int ms_lo = (a - lo) / MS, ms_hi = (a + Bx - 1 - lo) / MS;
+            if (ms < ms_lo) {
+                // the macro-strip dropped out of the band for good: take over the one NW further right
+                ms += NW;
+                if (ms == msn) {
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        sg0[i] = n0[i]; sg1[i] = n1[i]; sg2[i] = n2[i]; sg3[i] = n3[i];
+                        ug[i] = nu[i]; gg[i] = ng[i]; ig[i] = ni[i];
+                    }
+                    gleft = gleftn;
+                } else {
+                    while (ms < ms_lo) ms += NW;
+                    V2_LOAD(ms, sg0, sg1, sg2, sg3, ug, gg, ig, gleft)
+                }
+                msn = ms + NW;
+                V2_LOAD(msn, n0, n1, n2, n3, nu, ng, ni, gleftn)
+                ran_prev = 0;
+                continue;
+            }
+            if (ms > ms_hi) {                               // no work for this wave in row x
+                ran_prev = 0;
+                V2_NEXT_ROW()
+                continue;
+            }
+            // ---- inputs of (x, ms): written by the left neighbour before the last barrier?
+            const int y0 = lo + ms * MS;
+            const int yq = y0 - 1;
+            const bool needP = ms > ms_lo;
+            const bool needM = x > 0 && yq >= a_prev && yq < a_prev + Bx_prev;
+            const bool needT = x > 0 && ((yq >= a_prev + Bx_prev) || !ran_prev);
+            const uint4 eP4 = mb[wl][x & (V2_D - 1)];
+            const uint4 eM4 = mb[wl][(x - 1) & (V2_D - 1)];
+            const uint2 eT2 = ptb[(x - 1) & (V2_PD - 1)];
+            const unsigned ePx = UNI(eP4.x), ePy = UNI(eP4.y), ePz = UNI(eP4.z);
+            const unsigned eMy = UNI(eM4.y), eMz = UNI(eM4.z);
+            const unsigned eTx = UNI(eT2.x), eTy = UNI(eT2.y);
+            const bool ready = (!needP || ePz == (unsigned)(x + 1)) && (!needM || eMz == (unsigned)x) &&
+                               (!needT || eTy == (unsigned)x);
+            if (!ready) break;
+            --budget;
+            int Mleft = (int)PWR_INF;
+            if (x == 0) Mleft = 0;
+            else if (yq < a_prev) Mleft = (int)PWR_INF;                              // PW:276
+            else if (needM) Mleft = (int)eMy;
+            else Mleft = gleft + (int)eTx;                                           // PW:285-295
+            const int P_in = needP ? (int)ePx : PWR_BIG;
+            if (x > 0 && !ran_prev) {
+#pragma unroll
+                for (int i = 0; i < C; ++i) Mprev[i] = (unsigned)(gg[i] + (int)eTx);
+            }
+            if ((x >> 4) != gacc) { V2_FLUSH() gacc = x >> 4; }
+            const unsigned bit = 1u << (15 - (x & 15));
+            const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+            int t3[C];
+            switch (sx) {                                                            // PW:1503 Score(y, Seq_Bases[x])
+            case 0: V2_CASE(sg0) break;
+            case 1: V2_CASE(sg1) break;
+            case 2: V2_CASE(sg2) break;
+            default: V2_CASE(sg3) break;
+            }
+            const int rel0 = y0 + lc - a;
+            int tg[C];
+            int run = PWR_BIG;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bx) ? t3[i] : PWR_BIG;
+                run = min(run, tg[i]);
+            }
+            const int incl = wave_incl_min(run);
+            const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
+            const int P_end = min(P_in, __builtin_amdgcn_readlane(incl, 63));
+            int p = min(P_in, excl);
+            if (x != L - 1) {
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    accA[i] |= (tg[i] >= p) ? bit : 0u;
+                    p = min(p, tg[i]);
+                    Mprev[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
+                }
+            } else {
+                // last row: PW:1386 "M == M(x,y-1)" also moves left; keep the row for the entry scan
+                unsigned Mn[C];
+                unsigned fa = 0;
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    fa |= (tg[i] >= p) ? (1u << i) : 0u;
+                    p = min(p, tg[i]);
+                    Mn[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
+                }
+                const unsigned mrow = needP ? ePy : PWR_INF;
+                const unsigned left0 = (unsigned)__builtin_amdgcn_update_dpp((int)mrow, (int)Mn[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const unsigned lf = i ? Mn[i > 0 ? i - 1 : 0] : left0;
+                    const bool inb = (unsigned)(rel0 + i) < (unsigned)Bx;
+                    if (((fa >> i) & 1u) || (inb && Mn[i] == lf)) accA[i] |= bit;
+                    lastM[wave * MS + lc + i] = inb ? Mn[i] : 0xffffffffu;
+                    Mprev[i] = Mn[i];
+                }
+            }
+            if (lane == 63) {
+                mb[wave][x & (V2_D - 1)] = make_uint4((unsigned)P_end, Mprev[C - 1], (unsigned)(x + 1), 0u);
+                if (ms == ms_hi) ptb[x & (V2_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)(x + 1));
+            }
+            ran_prev = 1;
+            V2_NEXT_ROW()
+        }
+        __syncthreads();
+        if (UNI(__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= NW) break;
+    }
+    if (round >= max_rounds) {
+        if (tid == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+        return;
+    }
+    if (tid == 0) {
+        m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
+        m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
+        m->rounds = round;
         atomicAdd(&st.hdr->cells_computed, m->cells);
     }
 }
@@ -1504,7 +1763,8 @@ struct pwr_ctx {
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
     int threads = 256;
-    int fill_mode = 2;                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 2: wave pipeline in lock-step rounds (k_fill_ls)
+    int fill_mode = 3;
+    int wp_waves = 9;                     // waves per DP of the v2 wave pipeline: 9 (2 columns per lane) or 5 (4 per lane)                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 2: wave pipeline in lock-step rounds (k_fill_ls)
     int cells_per_thread = 1;
     // stats
     pwr_stats stats{};
@@ -1643,7 +1903,9 @@ static void host_trim(pwr_ctx *c)
 static int alloc_jobs(pwr_ctx *c, int njobs)
 {
     JobBufs &jb = c->jb;
-    const int NC = c->fill_mode ? 9 * 64 * (c->B <= 1024 ? 2 : 4) : c->threads * c->cells_per_thread;
+    if (c->B > 1000 || c->fill_mode != 3) c->wp_waves = 9;
+    const int wpC = c->wp_waves == 8 ? 3 : c->wp_waves == 5 ? 4 : c->wp_waves == 4 ? 6 : c->wp_waves == 3 ? 8 : (c->B <= 1024 ? 2 : 4);
+    const int NC = c->fill_mode ? c->wp_waves * 64 * wpC : c->threads * c->cells_per_thread;
     jb.layout = c->fill_mode ? 1 : 0;
     jb.Lmax = std::max(c->Lmax, 1);
     jb.colcap = c->st.colcap;
@@ -1653,6 +1915,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     if ((rc = dmalloc(c, &jb.meta, njobs))) return rc;
     if ((rc = dmalloc(c, &jb.way, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.rec, (size_t)njobs * jb.colcap))) return rc;
+    if ((rc = dmalloc(c, &jb.rec2, (size_t)njobs * jb.colcap * 2))) return rc;
     if ((rc = dmalloc(c, &jb.mark, (size_t)njobs * jb.colcap))) return rc;
     if ((rc = dmalloc(c, &jb.mark2, (size_t)njobs * jb.colcap))) return rc;
     if ((rc = dmalloc(c, &jb.dirs, (size_t)njobs * jb.dirstride))) return rc;
@@ -1669,7 +1932,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
 static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
-    dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.rec); dfree(c, jb.mark); dfree(c, jb.mark2);
+    dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.rec); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
     dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.lastM); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
@@ -1842,7 +2105,14 @@ static int launch_fill(pwr_ctx *c, int njobs)
         c->ev_used++;
         HIPC(hipEventRecord(e0, c->stream));
     }
-    if (c->fill_mode == 2) {
+    if (c->fill_mode == 3) {
+        if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v2<5, 4>), dim3(njobs), dim3(5 * 64), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v2<8, 3>), dim3(njobs), dim3(8 * 64), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v2<4, 6>), dim3(njobs), dim3(4 * 64), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v2<3, 8>), dim3(njobs), dim3(3 * 64), 0, c->stream, c->st, c->jb);
+        else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v2<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
+        else hipLaunchKernelGGL((k_fill_v2<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
+    } else if (c->fill_mode == 2) {
         if (c->B <= 1024) hipLaunchKernelGGL((k_fill_ls<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_ls<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
     } else if (c->fill_mode == 1) {
@@ -2082,7 +2352,8 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!c || !key) return PWR_ERR_ARG;
     if (!strcmp(key, "window")) { if (value < 1 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
-    if (!strcmp(key, "fill")) { if (c->on_device || value < 0 || value > 2) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
+    if (!strcmp(key, "fill")) { if (c->on_device || value < 0 || value > 3) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
+    if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
     if (!strcmp(key, "threads")) {
         if (c->on_device || (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)) return PWR_ERR_ARG;
         c->threads = (int)value;
@@ -2130,6 +2401,16 @@ extern "C" int pwr_debug_last_job(pwr_ctx *c, int *L, int *entry, int *W, int *w
     if (way && n > 0) HIPC(hipMemcpy(way, c->jb.way, sizeof(int) * n, hipMemcpyDeviceToHost));
     if (newcol && n > 0) HIPC(hipMemcpy(newcol, c->jb.newcol, sizeof(int) * n, hipMemcpyDeviceToHost));
     return PWR_OK;
+}
+
+extern "C" int pwr_debug_rounds(pwr_ctx *c)
+{
+    if (!c || !c->on_device) return PWR_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return PWR_ERR_DEVICE;
+    JobMeta m;
+    if (hipMemcpy(&m, c->jb.meta, sizeof m, hipMemcpyDeviceToHost) != hipSuccess) return PWR_ERR_DEVICE;
+    return m.rounds;
 }
 
 // shader clock the fill kernel of job 0 ran at: delta s_memtime / delta s_memrealtime (100 MHz)
