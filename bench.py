@@ -148,7 +148,7 @@ def main():
                                    f"one step = one realignment round",
                        "rows": T, "columns_in": W0, "columns_now": W1, "bandwidth": args.bandwidth,
                        "window": args.window, "score_before": score0, "score_after": score1,
-                       "rows_committed": st["rows_committed"], "rows_recomputed": st["rows_recomputed"], "batches": st["batches"],
+                       "rows_committed": st["rows_committed"], "rows_recomputed": st["rows_recomputed"], "batches": st["batches"], "rows_changed": st["rows_changed"], "reject_reason": st["reject_reason"],
                        "fill_threads": args.threads, "shader_clock_mhz_last_fill": round(clk_mhz),
                        "generate_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -11,7 +11,8 @@ class PwrStats(ctypes.Structure):
     _fields_ = [("cells_reference", ctypes.c_uint64), ("cells_computed", ctypes.c_uint64),
                 ("fill_launches", ctypes.c_uint64), ("fill_ms", ctypes.c_double),
                 ("rows_committed", ctypes.c_uint64), ("rows_recomputed", ctypes.c_uint64),
-                ("batches", ctypes.c_uint64)]
+                ("batches", ctypes.c_uint64), ("rows_changed", ctypes.c_uint64),
+                ("reject_reason", ctypes.c_uint64 * 4)]
 
 
 # every symbol include/pwr.h declares

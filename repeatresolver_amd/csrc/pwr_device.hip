@@ -40,6 +40,8 @@ struct Hdr {                       // lives in device memory, one per context
     int version;                   // bumped by every commit; columns carry the version that last changed them
     unsigned long long cells_computed;
     unsigned long long cells_reference;
+    unsigned long long rows_changed;   // commits that changed at least one column
+    unsigned long long fail_reason[4]; // why speculative jobs were rejected: 0 ends/length, 1 left clamp, 2 right clamp, 3 newer column
 };
 
 struct Tally {                     // 32 B per column slot
@@ -1356,9 +1358,9 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
 {
     const int job = blockIdx.x, lane = threadIdx.x;
     JobMeta *m = &jb.meta[job];
-    const int L = m->L;
+    const int L = UNI(m->L);
     if (L <= 0 || !m->ok) return;
-    const int W = m->W, B = st.B, H = st.H, RS = jb.NC, lo = m->lo;
+    const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
     const unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
@@ -1388,6 +1390,7 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
             const unsigned lastval = lastM[(a + B - 1 - lo) % RS];
             if (entry < 0 || lastval <= vmin) entry = W - 1;
         }
+        entry = UNI(entry);
         y = entry;
         if (lane == 0) m->entry = entry;
         if (entry < 0) err = 4;
@@ -1401,6 +1404,7 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
     int wnxt = way[max(blk * 64 - 64 + lane, 0)];
     int ncreg = 0;
     while (x >= 0 && !err) {
+        x = UNI(x); y = UNI(y); blk = UNI(blk); gcur = UNI(gcur); yb = UNI(yb); gpre = UNI(gpre); ybpre = UNI(ybpre); nnew = UNI(nnew);
         if ((x >> 6) != blk) {
             if (blk * 64 + lane < L) newcol[blk * 64 + lane] = ncreg;
             blk = x >> 6;
@@ -1503,7 +1507,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     const int nfree = h->nfree, nslots = h->nslots;
     const int take = min(nnew, nfree);
     const unsigned newver = (unsigned)h->version + 1u;
-    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; }                // [0] freed slots, [1] some column lost its last base
+    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[3] = 0; }    // [0] freed slots, [1] some column lost its last base, [3] any change
     for (int y = ny0 + tid; y <= nyL; y += COMMIT_NT) mark2[y - lo] = 0;
     __syncthreads();
     for (int x = tid; x < L; x += COMMIT_NT) {
@@ -1563,6 +1567,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
                 if (b == 4) w4 = v;
             }
             st.colver[slot] = newver;
+            s_i[3] = 1;
             if (w4 == 0) s_i[1] = 1;
         }
     }
@@ -1620,6 +1625,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         }
         h->version = (int)newver;
         h->cells_reference += m->cells;
+        if (s_i[3] || nnew > 0) h->rows_changed += 1;
     }
     __syncthreads();
 }
@@ -1644,18 +1650,20 @@ __device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsig
     const int lo2 = st.rank[m->slot_lo], hi2 = st.rank[m->slot_hi];
     bool ok = lo2 >= 0 && lo2 < W && hi2 >= 0 && hi2 < W;
     ok = ok && order[lo2] == m->slot_lo && order[hi2] == m->slot_hi && (hi2 - lo2) == (hi - lo);
+    int why = ok ? -1 : 0;
     const int d = lo2 - lo;
     if (ok) {
         const int way0 = way[0], wayL = way[L - 1], H = st.H, B = st.B;
-        if (d != 0 && !(way0 - H >= 1 && way0 + d - H >= 1)) ok = false;           // left clamp PW:1496
+        if (d != 0 && !(way0 - H >= 1 && way0 + d - H >= 1)) { ok = false; why = 1; }           // left clamp PW:1496
         const int aL = max(0, wayL - H);
         const bool far_old = aL + B <= m->W - 1, far_new = aL + d + B <= W - 1;
-        if (!(far_old && far_new) && (W - hi2) != (m->W - hi)) ok = false;         // right clamp PW:1497/1505
+        if (ok && !(far_old && far_new) && (W - hi2) != (m->W - hi)) { ok = false; why = 2; }   // right clamp PW:1497/1505
     }
     unsigned mx = 0;
     if (ok) for (int y = lo2 + tid; y <= hi2; y += COMMIT_NT) mx = max(mx, st.colver[order[y]]);
     mx = ~block_min_u32<COMMIT_NT>(~mx, sh);
-    if (ok && mx > (unsigned)m->ver) ok = false;
+    if (ok && mx > (unsigned)m->ver) { ok = false; why = 3; }
+    if (tid == 0 && why >= 0) st.hdr->fail_reason[why] += 1;
     if (tid == 0) s_i[2] = ok ? 1 : 0;
     __syncthreads();
     ok = s_i[2] != 0;
@@ -1759,12 +1767,12 @@ struct pwr_ctx {
     int W_ub = 0;                         // host upper bound of the device width
     int nslots_ub = 0;
     // options
-    int window = 32;
+    int window = 8;
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
     int threads = 256;
     int fill_mode = 3;
-    int wp_waves = 9;                     // waves per DP of the v2 wave pipeline: 9 (2 columns per lane) or 5 (4 per lane)                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 2: wave pipeline in lock-step rounds (k_fill_ls)
+    int wp_waves = 5;                     // waves per DP of the v2 wave pipeline: 9/8/5/4/3 with 2/3/4/6/8 columns per lane                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 2: wave pipeline in lock-step rounds (k_fill_ls)
     int cells_per_thread = 1;
     // stats
     pwr_stats stats{};
@@ -2196,6 +2204,8 @@ static int check_status(pwr_ctx *c)
     c->W_ub = h.W; c->nslots_ub = h.nslots;
     c->stats.cells_computed = h.cells_computed;
     c->stats.cells_reference = h.cells_reference;
+    c->stats.rows_changed = h.rows_changed;
+    for (int i = 0; i < 4; ++i) c->stats.reject_reason[i] = h.fail_reason[i];
     if ((rc = drain_events(c))) return rc;
     return h.status;
 }
@@ -2381,7 +2391,7 @@ extern "C" int pwr_reset_stats(pwr_ctx *c)
     if (c->on_device) {
         if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
         HIPC(hipStreamSynchronize(c->stream));
-        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 2 * sizeof(unsigned long long)));
+        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 7 * sizeof(unsigned long long)));
     }
     return PWR_OK;
 }

@@ -94,7 +94,9 @@ class PWReAligner:
     def stats(self):
         s = _lib.PwrStats()
         _check(self._lib.pwr_get_stats(self._h, ctypes.byref(s)), "pwr_get_stats")
-        return {f: getattr(s, f) for f, _ in s._fields_}
+        d = {f: getattr(s, f) for f, _ in s._fields_}
+        d["reject_reason"] = list(d["reject_reason"])
+        return d
 
     def reset_stats(self):
         _check(self._lib.pwr_reset_stats(self._h), "pwr_reset_stats")
