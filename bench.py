@@ -83,6 +83,10 @@ def main():
     from repeatresolver_amd import datagen as dg
     from repeatresolver_amd.realigner import PWReAligner
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
     cfg = dg.CONFIGS[args.workload]
     cfg = dg.SimConfig(**{**cfg.__dict__, "seed": args.seed + rank})
     t0 = time.time()
@@ -91,12 +95,15 @@ def main():
     T, W0 = msa.shape
     del msa
     gen_s = time.time() - t0
+    note(f"generated {T} rows x {W0} columns in {gen_s:.1f} s")
 
     g = PWReAligner(rows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, threads=args.threads, fill=args.fill, waves=args.waves)
     g.trim_ends()
     score0 = g.total_score()            # first device call: uploads the MSA into HBM
-    for _ in range(args.warmup):
+    note(f"resident in HBM, score {score0}")
+    for i in range(args.warmup):
         g.realign_round()
+        note(f"warm-up round {i + 1} done")
     g.reset_stats()
 
     def fence():
@@ -106,8 +113,9 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         g.realign_round()
+        note(f"timed round {i + 1} done")
     fence()
     dt = time.perf_counter() - t0
     st = g.stats()
@@ -159,6 +167,7 @@ def main():
                          "note": "achieved = cells computed by k_fill x 4 B / sum of HIP-event launch durations"},
         }
         if world == 1 and not args.no_cpu_baseline:
+            note("timing the CPU baseline on a bounded sample")
             out["cpu_baseline"] = cpu_baseline(rows, args.bandwidth)
         print(json.dumps(out), flush=True)
     g.close()

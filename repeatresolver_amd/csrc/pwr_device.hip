@@ -1434,17 +1434,29 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
                     for (int q = 0; q < 4; ++q) pre[q] = dirs[(size_t)(g - 1) * RS + (want + 64 * q + lane - lo) % RS];
                 }
             }
+            {   // common case: the answer lies in the 64-cell sub-window that holds yc
+                const int q0 = (yc - yb) >> 6;
+                const uint32_t wq = q0 == 0 ? win[0] : q0 == 1 ? win[1] : q0 == 2 ? win[2] : win[3];
+                const int cy = yb + 64 * q0 + lane;
+                const unsigned long long mk = __ballot(cy <= yc && cy >= a && !((wq >> sh) & 1u));
+                if (mk) {
+                    const int t = 63 - __builtin_clzll(mk);
+                    found = yb + 64 * q0 + t;
+                    const unsigned long long ck = __ballot((wq >> (16 + sh)) & 1u);
+                    cbit = (int)((ck >> t) & 1ull);
+                } else {
 #pragma unroll
-            for (int q = 3; q >= 0; --q) {
-                if (found < 0) {
-                    const int cy = yb + 64 * q + lane;
-                    const bool abit = (win[q] >> sh) & 1u;
-                    const unsigned long long mk = __ballot(cy <= yc && cy >= a && !abit);
-                    if (mk) {
-                        const int t = 63 - __builtin_clzll(mk);
-                        found = yb + 64 * q + t;
-                        const unsigned long long ck = __ballot((win[q] >> (16 + sh)) & 1u);
-                        cbit = (int)((ck >> t) & 1ull);
+                    for (int q = 2; q >= 0; --q) {
+                        if (found < 0 && q < q0) {
+                            const int cy2 = yb + 64 * q + lane;
+                            const unsigned long long mk2 = __ballot(cy2 >= a && !((win[q] >> sh) & 1u));
+                            if (mk2) {
+                                const int t = 63 - __builtin_clzll(mk2);
+                                found = yb + 64 * q + t;
+                                const unsigned long long ck = __ballot((win[q] >> (16 + sh)) & 1u);
+                                cbit = (int)((ck >> t) & 1ull);
+                            }
+                        }
                     }
                 }
             }
@@ -1771,6 +1783,7 @@ struct pwr_ctx {
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
     int threads = 256;
+    int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int fill_mode = 3;
     int wp_waves = 5;                     // waves per DP of the v2 wave pipeline: 9/8/5/4/3 with 2/3/4/6/8 columns per lane                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 2: wave pipeline in lock-step rounds (k_fill_ls)
     int cells_per_thread = 1;
@@ -1999,7 +2012,7 @@ static int upload(pwr_ctx *c)
     DState &st = c->st;
     st = DState{};
     st.T = T; st.B = c->B; st.H = c->H; st.Lmax = c->Lmax;
-    st.colcap = 2 * W + 2 * c->Lmax + 8192;
+    st.colcap = c->cap_slack ? 2 * W + 2 * c->Lmax + c->cap_slack : W + c->Lmax + 128;
     st.slotcap = st.colcap;
     int rc;
     Hdr hdr{};
@@ -2261,7 +2274,9 @@ extern "C" int pwr_realign_round(pwr_ctx *c)
     int k = 0;                                                                 // PW:1695: rows in input order
     double ema = c->batch_ema;
     while (k < c->T) {
-        int n = (int)(2.0 * ema + 2.5);
+        // A batch costs as long as its longest fill; rows that overlap the rows before them are almost
+        // always invalidated while the MSA is still moving, so speculate just past the running mean.
+        int n = (int)(ema + 1.6);
         n = std::max(1, std::min(n, std::min(c->window, c->T - k)));
         int done = 0;
         if ((rc = run_batch(c, k, n, &done))) return rc;
@@ -2363,6 +2378,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "window")) { if (value < 1 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
     if (!strcmp(key, "fill")) { if (c->on_device || value < 0 || value > 3) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
+    if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
     if (!strcmp(key, "threads")) {
         if (c->on_device || (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)) return PWR_ERR_ARG;

@@ -51,3 +51,39 @@ def test_cli_usage_and_missing_file(tmp_path):
     p = subprocess.run([cli, str(tmp_path / "nope"), "-o", str(tmp_path / "o")], capture_output=True)
     assert p.returncode == 1                                                             # PW:121
     assert p.stdout.decode().splitlines()[-1] == "MA is missing."
+
+
+def test_argument_and_input_errors(tmp_path):
+    """Error behaviour of the boundary that needs no GPU (PW:121, PW:134, PW:14)."""
+    _build()
+    import ctypes
+    from repeatresolver_amd import _lib
+    from repeatresolver_amd.realigner import PWReAligner, PwrError
+    import pytest
+    with pytest.raises(PwrError) as e:
+        PWReAligner([b"acgx", b"acgt"])                    # not in the alphabet of PW:165-222
+    assert e.value.code == -4
+    with pytest.raises(PwrError) as e:
+        PWReAligner([b"acgt"], bandwidth=2001)             # Max_Bandwidth, PW:14
+    assert e.value.code == -5
+    with pytest.raises(PwrError):
+        PWReAligner([b"acgt"], bandwidth=0)
+    lib = _lib.load()
+    lib.pwr_read_msa_file.restype = ctypes.c_int
+    lib.pwr_read_msa_file.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                      ctypes.POINTER(ctypes.POINTER(ctypes.c_ubyte)), ctypes.c_char_p, ctypes.c_size_t]
+    T, W = ctypes.c_int(), ctypes.c_int()
+    txt = ctypes.POINTER(ctypes.c_ubyte)()
+    err = ctypes.create_string_buffer(256)
+
+    def read(data):
+        p = tmp_path / "m.msa"
+        p.write_bytes(data)
+        return lib.pwr_read_msa_file(str(p).encode(), ctypes.byref(T), ctypes.byref(W), ctypes.byref(txt), err, 256)
+    assert read(b"acgt\nac-t\n") == 0 and (T.value, W.value) == (2, 4)
+    assert read(b"acgt\nacgt") == -4                      # last line without newline, PW:134
+    assert read(b"acgt\nacg\n") == -4                     # unequal lengths: refused (SURVEY R3)
+    assert read(b"") == -4
+    assert lib.pwr_read_msa_file(str(tmp_path / "nope").encode(), ctypes.byref(T), ctypes.byref(W),
+                                 ctypes.byref(txt), err, 256) == -4
+    assert err.value == b"MA is missing."                  # PW:121

@@ -140,3 +140,69 @@ def test_sections_on_gpu(oracle):
     for p, sec in enumerate(secs):
         exp, _ = _oracle_worker(sec, 200, 0, 2)
         assert got[p] == exp
+
+
+@pytest.mark.parametrize("bw", [2000, 1500, 1024, 1])
+def test_wide_and_degenerate_bandwidths(bw, oracle):
+    """Bandwidths above 1000 use the 9-wave / 4-columns-per-lane geometry; 1 is the smallest band."""
+    from repeatresolver_amd.realigner import PWReAligner
+    rows = split_rows(golden_input("toy_a_b1000"))
+    g = PWReAligner(rows, bandwidth=bw)
+    g.trim_ends()
+    h = oracle.create(rows, bw)
+    oracle.lib.pwo_trim(h)
+    for _ in range(2):
+        g.realign_round()
+        oracle.lib.pwo_realign_round(h)
+        assert g.total_score() == oracle.lib.pwo_total_score(h)
+        assert g.export_rows() == oracle.export(h)
+    oracle.lib.pwo_destroy(h)
+    g.close()
+
+
+def test_capacity_regrow_and_out_of_order_rows(oracle):
+    """Tight allocation (slack 0) forces the device arrays to be regrown while columns are being
+    opened; rows are realigned in an arbitrary order through pwr_realign_row."""
+    from repeatresolver_amd.realigner import PWReAligner
+    rows = split_rows(golden_input("lowcov_b300"))
+    g = PWReAligner(rows, bandwidth=300, slack=0)
+    g.trim_ends()
+    h = oracle.create(rows, 300)
+    oracle.lib.pwo_trim(h)
+    T = len(rows)
+    order = [(7 * i + 3) % T for i in range(T)] * 2
+    for k in order:
+        g.realign_row(k)
+        assert oracle.lib.pwo_realign_row(h, k) == 0
+    assert g.total_score() == oracle.lib.pwo_total_score(h)
+    assert g.export_rows() == oracle.export(h)
+    for _ in range(2):
+        g.realign_round()
+        oracle.lib.pwo_realign_round(h)
+    assert g.total_score() == oracle.lib.pwo_total_score(h)
+    assert g.export_rows() == oracle.export(h)
+    oracle.lib.pwo_destroy(h)
+    g.close()
+
+
+def test_rows_without_bases_and_unsupported_states():
+    from repeatresolver_amd.realigner import PWReAligner, PwrError
+    rows = [b"acgt-acgtacg", b"------------", b"ac-tgacgtacg", b"            ", b"-cgtgacgta--"]
+    g = PWReAligner(rows, bandwidth=6, window=4)
+    g.trim_ends()
+    g.realign_round()                     # rows 1 and 3 have no bases: PW:1488
+    out = g.export_rows()
+    assert out[1].strip() == b"" and out[3].strip() == b""
+    g.close()
+    bad = [b"acgtacgt", b"ac  acgt", b"acgtacgt"]          # blanks between bases of one row
+    g = PWReAligner(bad, bandwidth=6)
+    g.trim_ends()
+    with pytest.raises(PwrError) as e:
+        g.realign_round()
+    assert e.value.code == -7
+    g.close()
+    g = PWReAligner([b"--acgt--", b"acgtacgt"], bandwidth=6)   # not trimmed: '-' outside the bases
+    with pytest.raises(PwrError) as e:
+        g.realign_round()
+    assert e.value.code == -7
+    g.close()
