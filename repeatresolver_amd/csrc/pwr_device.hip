@@ -1218,12 +1218,109 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
         }                                                                                        \
     }
 
+#ifdef PWR_STAMPS
+    unsigned long long fs0 = 0, fs1 = 0, fs2 = 0, fs3 = 0, fsn = 0;
+#endif
     for (; round < max_rounds; ++round) {
         int budget = V2_R;
         while (budget > 0) {
             // loop-carried control state is wave-uniform; say so, so it lives in SGPRs and branches are scalar
             finished = UNI(finished);
             if (finished) break;
+            ran_prev = UNI(ran_prev); gacc = UNI(gacc); blk = UNI(blk); ms = UNI(ms); gleft = UNI(gleft);
+            // ---- fast path: a run of ordinary rows (same macro-strip in the band, not the first / last row, same
+            //      16-row group and 64-row block, previous row done by this wave) as straight-line code.
+            //      The left neighbour's mailbox entry of the NEXT row is fetched while the current row is computed.
+            bool not_ready = false;
+            {
+                uint4 fP4 = mb[wl][x & (V2_D - 1)];
+                uint4 fM4 = mb[wl][(x - 1) & (V2_D - 1)];
+                while (budget > 0) {
+#ifdef PWR_STAMPS
+                    const unsigned long long f0 = __builtin_amdgcn_s_memtime();
+#endif
+                    const int Bxf = min(B, W - a);
+                    const int y0f = lo + ms * MS;
+                    const bool simple = (a < y0f + MS) && (a + Bxf > y0f) && x > 0 && ran_prev && x < L - 1 &&
+                                        (x >> 4) == gacc && ((x + 1) >> 6) == blk;
+                    if (!simple) break;
+                    const int yqf = y0f - 1;
+                    const bool needPf = a < y0f;                                     // ms > ms_lo
+                    const bool inMf = yqf >= a_prev && yqf < a_prev + Bx_prev;
+                    const bool needTf = yqf >= a_prev + Bx_prev;
+                    unsigned fPx = UNI(fP4.x), fPy = UNI(fP4.y), fPz = UNI(fP4.z), fMy = UNI(fM4.y), fMz = UNI(fM4.z);
+                    unsigned fTx = 0;
+                    bool readyf = (!needPf || fPz == (unsigned)(x + 1)) && (!inMf || fMz == (unsigned)x);
+                    if (!readyf) {                                                   // the prefetched copy may be stale: look again
+                        fP4 = mb[wl][x & (V2_D - 1)];
+                        fM4 = mb[wl][(x - 1) & (V2_D - 1)];
+                        fPx = UNI(fP4.x); fPy = UNI(fP4.y); fPz = UNI(fP4.z); fMy = UNI(fM4.y); fMz = UNI(fM4.z);
+                        readyf = (!needPf || fPz == (unsigned)(x + 1)) && (!inMf || fMz == (unsigned)x);
+                    }
+                    if (readyf && needTf) {
+                        const uint2 fT2 = ptb[(x - 1) & (V2_PD - 1)];
+                        fTx = UNI(fT2.x);
+                        readyf = UNI(fT2.y) == (unsigned)x;
+                    }
+                    if (!readyf) { not_ready = true; break; }
+#ifdef PWR_STAMPS
+                    const unsigned long long f1 = __builtin_amdgcn_s_memtime();
+#endif
+                    --budget;
+                    // next row's entry: this row's entry also carries M_last(x) = what row x+1 needs as M_last(x)
+                    fM4 = fP4;
+                    fP4 = mb[wl][(x + 1) & (V2_D - 1)];
+                    (void)fPy;
+                    const int Mleftf = inMf ? (int)fMy : (needTf ? gleft + (int)fTx : (int)PWR_INF);
+                    const int P_inf = needPf ? (int)fPx : PWR_BIG;
+                    const unsigned bit = 1u << (15 - (x & 15));
+                    const int pm1_0 = __builtin_amdgcn_update_dpp(Mleftf, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+                    int t3[C];
+                    switch (sx) {
+                    case 0: V2_CASE(sg0) break;
+                    case 1: V2_CASE(sg1) break;
+                    case 2: V2_CASE(sg2) break;
+                    default: V2_CASE(sg3) break;
+                    }
+#ifdef PWR_STAMPS
+                    const unsigned long long f2 = __builtin_amdgcn_s_memtime();
+#endif
+                    const int rel0 = y0f + lc - a;
+                    int tg[C];
+                    int run = PWR_BIG;
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bxf) ? t3[i] : PWR_BIG;
+                        run = min(run, tg[i]);
+                    }
+                    const int incl = wave_incl_min(run);
+                    const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
+                    const int P_end = min(P_inf, __builtin_amdgcn_readlane(incl, 63));
+#ifdef PWR_STAMPS
+                    const unsigned long long f3 = __builtin_amdgcn_s_memtime();
+#endif
+                    int p = min(P_inf, excl);
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        accA[i] |= (tg[i] >= p) ? bit : 0u;
+                        p = min(p, tg[i]);
+                        Mprev[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
+                    }
+                    if (lane == 63) {
+                        mb[wave][x & (V2_D - 1)] = make_uint4((unsigned)P_end, Mprev[C - 1], (unsigned)(x + 1), 0u);
+                        if (a + Bxf <= y0f + MS) ptb[x & (V2_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)(x + 1));
+                    }
+                    a_prev = a; Bx_prev = Bxf;
+                    ++x;
+                    a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+                    sx = __builtin_amdgcn_readlane(scur, x & 63);
+#ifdef PWR_STAMPS
+                    { const unsigned long long f4 = __builtin_amdgcn_s_memtime(); fs0 += f1 - f0; fs1 += f2 - f1; fs2 += f3 - f2; fs3 += f4 - f3; ++fsn; }
+#endif
+                }
+            }
+            if (not_ready || budget <= 0) break;
+
             x = UNI(x); ms = UNI(ms); msn = UNI(msn); a = UNI(a); a_prev = UNI(a_prev); Bx_prev = UNI(Bx_prev);
             sx = UNI(sx); gacc = UNI(gacc); blk = UNI(blk); gleft = UNI(gleft); gleftn = UNI(gleftn); ran_prev = UNI(ran_prev);
             const int Bx = min(B, W - a);
@@ -1342,6 +1439,9 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
         if (tid == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
         return;
     }
+#ifdef PWR_STAMPS
+    if (lane == 0) printf("wave%d fast: mailbox %llu cells %llu scan %llu finish %llu n %llu rounds %d\n", wave, fs0, fs1, fs2, fs3, fsn, round);
+#endif
     if (tid == 0) {
         m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
         m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
@@ -1405,6 +1505,28 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
     int ncreg = 0;
     while (x >= 0 && !err) {
         x = UNI(x); y = UNI(y); blk = UNI(blk); gcur = UNI(gcur); yb = UNI(yb); gpre = UNI(gpre); ybpre = UNI(ybpre); nnew = UNI(nnew);
+        // ---- fast path: rows of the current 16-row group / 64-row block whose answer lies in the
+        //      64-cell sub-window holding the current column -- straight-line, no memory access
+        while ((x >> 4) == gcur && (x >> 6) == blk) {
+            const int af = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+            const int ycf = min(y, af + min(B, W - af) - 1);
+            if (y < af || ycf < yb || ycf > yb + 255) break;
+            const int q0 = (ycf - yb) >> 6, shf = 15 - (x & 15);
+            const uint32_t wq = q0 == 0 ? win[0] : q0 == 1 ? win[1] : q0 == 2 ? win[2] : win[3];
+            const int cy = yb + 64 * q0 + lane;
+            const unsigned long long mk = __ballot(cy <= ycf && cy >= af && !((wq >> shf) & 1u));
+            if (!mk) break;
+            const int t = 63 - __builtin_clzll(mk);
+            const int yy = yb + 64 * q0 + t;
+            const int cb = (int)((__ballot((wq >> (16 + shf)) & 1u) >> t) & 1ull);
+            ncreg = (lane == (x & 63)) ? ((yy << 1) | (cb ^ 1)) : ncreg;
+            y = yy - cb;                                        // diag: column to the left, up: stay
+            nnew += cb ^ 1;
+            --x;
+            if (x < 0 || y < 0) break;
+        }
+        if (x < 0) break;
+        if (y < 0) { err = 3; break; }
         if ((x >> 6) != blk) {
             if (blk * 64 + lane < L) newcol[blk * 64 + lane] = ncreg;
             blk = x >> 6;
