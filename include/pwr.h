@@ -45,12 +45,13 @@ typedef struct pwr_stats {
     uint64_t cells_computed;    /* DP cells the fill kernel actually computed (includes speculative
                                    fills that had to be repeated) */
     uint64_t fill_launches;     /* launches of the DP fill kernel */
-    double fill_ms;             /* sum of HIP-event durations of those launches (profiling on) */
+    double fill_ms;             /* sum of HIP-event durations of the timed launches (profiling on) */
     uint64_t rows_committed;    /* realignments committed (== Matrix_Filler calls with length>0) */
     uint64_t rows_recomputed;   /* speculative results discarded because their inputs changed */
     uint64_t batches;           /* speculative batches launched */
     uint64_t rows_changed;      /* committed realignments that changed the MSA */
     uint64_t reject_reason[4];  /* speculative rejections: interval ends/length, left clamp, right clamp, newer column */
+    uint64_t fill_launches_timed; /* launches covered by fill_ms (the first 65536 after a reset) */
 } pwr_stats;
 
 /* Replaces MMA_Einlesen (PW:93-241) for an in-memory matrix: `text` holds rows*width characters,
@@ -79,7 +80,7 @@ int pwr_dims(pwr_ctx *ctx, int *rows, int *width);
 int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
 
 /* Knobs and counters (ours). keys: "window" (max rows filled speculatively per batch, >= 1),
- * "profile" (1 = time every fill launch with HIP events), "fill" (DP fill kernel: 3 = k_fill_v2, the default; 2 = k_fill_ls; 1 = k_fill_wp; 0 = k_fill),
+ * "profile" (1 = time every fill launch with HIP events), "fill" (DP fill kernel: 3 = k_fill_v2, the default; 1 = k_fill_wp; 0 = k_fill),
  * "waves" (waves per DP of k_fill_v2: 9, 8, 5 (default), 4 or 3; bandwidths above 1000 always use 9), "threads" (work-group size of the DP fill: 64, 128, 256, 512 or 1024). */
 int pwr_set_option(pwr_ctx *ctx, const char *key, long value);
 int pwr_get_stats(pwr_ctx *ctx, pwr_stats *out);

@@ -838,275 +838,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill_wp(DState st, JobBufs jb)
 
 
 // ---------------------------------------------------------------------------------------------
-// fill, lock-step round form of the wave pipeline.  Same ownership as k_fill_wp (macro-strip ms of
-// 64*C columns -> wave ms mod NW, records and previous-row scores in registers, DPP scan inside the
-// wave) but the waves advance in rounds separated by ONE s_barrier: in a round every wave whose
-// inputs for its next DP row are present (left neighbour's running minimum / boundary score of
-// that row, tagged with the row number) computes that row and posts its own outputs; what it reads
-// was written before the last barrier, so there is no polling and no spin.  In steady state wave w
-// is one row behind wave w-1 and the work-group retires one DP row per round.
-// ---------------------------------------------------------------------------------------------
-#define LS_D 16
-#define LS_PD 64
-template <int NW, int C>
-__global__ __launch_bounds__(NW * 64) void k_fill_ls(DState st, JobBufs jb)
-{
-    constexpr int MS = 64 * C, RS = NW * MS;
-    __shared__ uint4 mb[NW][LS_D];                  // {P_end, M_last, tag = row + 1, -}
-    __shared__ uint2 ptb[LS_PD];                    // {Ptot, tag}
-    __shared__ int s_done;
-
-    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    JobMeta *m = &jb.meta[job];
-    const int L = m->L;
-    if (L <= 0 || !m->ok) return;
-    const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
-    for (int i = tid; i < NW * LS_D; i += NW * 64) (&mb[0][0])[i] = make_uint4(0, 0, 0, 0);
-    for (int i = tid; i < LS_PD; i += NW * 64) ptb[i] = make_uint2(0, 0);
-    if (tid == 0) s_done = 0;
-    __syncthreads();
-
-    const int lo = m->lo, hi = m->hi, W = m->W, B = st.B, H = st.H;
-    const int *way = jb.way + (size_t)job * jb.Lmax;
-    const unsigned *gbase = jb.gbase + (size_t)job * jb.Lmax;
-    const uint8_t *seq = st.seq + st.rowoff[m->k];
-    const uint4 *rec = jb.rec + (size_t)job * jb.colcap;
-    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
-    unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
-    const int wl = (wave + NW - 1) % NW;
-    const int lc = lane * C;
-
-    unsigned rx[C], ry[C], rz[C], rw[C], nx[C], ny[C], nz[C], nw[C];     // records (current / prefetched macro-strip)
-    unsigned gleft = 0, gleftn = 0;
-    int ms = wave, msn = wave + NW;
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const int y = lo + ms * MS + lc + i;
-        uint4 t4 = make_uint4(0, 0, 0, PWR_INF);
-        if (y <= hi) t4 = rec[y - lo];
-        rx[i] = t4.x; ry[i] = t4.y; rz[i] = t4.z; rw[i] = t4.w;
-        const int yn = lo + msn * MS + lc + i;
-        uint4 u4 = make_uint4(0, 0, 0, PWR_INF);
-        if (yn <= hi) u4 = rec[yn - lo];
-        nx[i] = u4.x; ny[i] = u4.y; nz[i] = u4.z; nw[i] = u4.w;
-    }
-    { const int yq = lo + ms * MS - 1; gleft = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
-    { const int yq = lo + msn * MS - 1; gleftn = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
-
-    unsigned Mprev[C], accA[C], accC[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) { Mprev[i] = 0; accA[i] = accC[i] = 0; }
-    bool ran_prev = false, finished = false;
-    int x = 0;                                              // this wave's next DP row
-    int blk = 0;
-    int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
-    unsigned gcur = gbase[min(lane, L - 1)];
-    int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
-    unsigned gnxt = gbase[min(64 + lane, L - 1)];
-    // row parameters of row x and of row x-1 (kept in SGPRs)
-    int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H), a_prev = 0, Bx_prev = 0;
-    unsigned gb = (unsigned)__builtin_amdgcn_readlane((int)gcur, 0), gb_prev = 0;
-    int sx = __builtin_amdgcn_readlane(scur, 0);
-    const int max_rounds = 4 * L + 64 * NW + 1024;
-    int round = 0;
-
-    for (; round < max_rounds; ++round) {
-        if (!finished) {
-            int Bx = min(B, W - a);
-            int ms_lo = (a - lo) / MS, ms_hi = (a + Bx - 1 - lo) / MS;
-            // rows in which this wave's macro-strip is not inside the band cost nothing: skip them
-            // (taking over the macro-strip NW further right when the current one is left behind)
-            for (;;) {
-                if (ms < ms_lo) {
-                    ms += NW;
-                    if (ms == msn) {
-#pragma unroll
-                        for (int i = 0; i < C; ++i) { rx[i] = nx[i]; ry[i] = ny[i]; rz[i] = nz[i]; rw[i] = nw[i]; }
-                        gleft = gleftn;
-                    } else {
-                        while (ms < ms_lo) ms += NW;
-#pragma unroll
-                        for (int i = 0; i < C; ++i) {
-                            const int y = lo + ms * MS + lc + i;
-                            uint4 t4 = make_uint4(0, 0, 0, PWR_INF);
-                            if (y <= hi) t4 = rec[y - lo];
-                            rx[i] = t4.x; ry[i] = t4.y; rz[i] = t4.z; rw[i] = t4.w;
-                        }
-                        const int yq = lo + ms * MS - 1;
-                        gleft = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u;
-                    }
-                    msn = ms + NW;
-#pragma unroll
-                    for (int i = 0; i < C; ++i) {
-                        const int yn = lo + msn * MS + lc + i;
-                        uint4 u4 = make_uint4(0, 0, 0, PWR_INF);
-                        if (yn <= hi) u4 = rec[yn - lo];
-                        nx[i] = u4.x; ny[i] = u4.y; nz[i] = u4.z; nw[i] = u4.w;
-                    }
-                    { const int yq = lo + msn * MS - 1; gleftn = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
-                    ran_prev = false;
-                    continue;
-                }
-                if (ms <= ms_hi) break;                     // a task
-                // no task in row x: keep the traceback words aligned and move on
-#pragma unroll
-                for (int i = 0; i < C; ++i) { accA[i] <<= 1; accC[i] <<= 1; }
-                if ((x & 15) == 15 || x == L - 1) {
-                    const int sh = 15 - (x & 15);
-                    uint32_t *d = dirs + (size_t)(x >> 4) * RS + (size_t)wave * MS + (size_t)lc;
-#pragma unroll
-                    for (int i = 0; i < C; ++i) {
-                        d[i] = ((accA[i] << sh) & 0xffffu) | (((accC[i] << sh) & 0xffffu) << 16);
-                        accA[i] = accC[i] = 0;
-                    }
-                }
-                ran_prev = false;
-                a_prev = a; Bx_prev = Bx; gb_prev = gb;
-                ++x;
-                if (x == L) { finished = true; break; }
-                if ((x >> 6) != blk) {
-                    blk = x >> 6;
-                    wcur = wnxt; scur = snxt; gcur = gnxt;
-                    wnxt = way[min(x + 64 + lane, L - 1)];
-                    snxt = seq[min(x + 64 + lane, L - 1)];
-                    gnxt = gbase[min(x + 64 + lane, L - 1)];
-                }
-                a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
-                gb = (unsigned)__builtin_amdgcn_readlane((int)gcur, x & 63);
-                sx = __builtin_amdgcn_readlane(scur, x & 63);
-                Bx = min(B, W - a);
-                ms_lo = (a - lo) / MS; ms_hi = (a + Bx - 1 - lo) / MS;
-            }
-            if (finished) {
-                if (lane == 0) atomicAdd(&s_done, 1);
-            } else {
-                // ---- are the inputs of (x, ms) there?  (everything read here was written before the last barrier)
-                const int y0 = lo + ms * MS;
-                const int yq = y0 - 1;
-                const bool needP = ms > ms_lo;
-                const bool needM = x > 0 && yq >= a_prev && yq < a_prev + Bx_prev;          // boundary score of row x-1
-                const bool needT = x > 0 && ((yq >= a_prev + Bx_prev) || !ran_prev);        // row minimum of row x-1
-                uint4 eP = mb[wl][x & (LS_D - 1)];
-                uint4 eM = mb[wl][(x - 1) & (LS_D - 1)];
-                uint2 eT = ptb[(x - 1) & (LS_PD - 1)];
-                eP.x = __builtin_amdgcn_readfirstlane(eP.x); eP.y = __builtin_amdgcn_readfirstlane(eP.y); eP.z = __builtin_amdgcn_readfirstlane(eP.z);
-                eM.y = __builtin_amdgcn_readfirstlane(eM.y); eM.z = __builtin_amdgcn_readfirstlane(eM.z);
-                eT.x = __builtin_amdgcn_readfirstlane(eT.x); eT.y = __builtin_amdgcn_readfirstlane(eT.y);
-                const bool ready = (!needP || eP.z == (unsigned)(x + 1)) && (!needM || eM.z == (unsigned)x) &&
-                                   (!needT || eT.y == (unsigned)x);
-                if (ready) {
-                    unsigned Mleft = PWR_INF;
-                    if (x == 0) Mleft = 0;
-                    else if (yq < a_prev) Mleft = PWR_INF;                                   // PW:276
-                    else if (needM) Mleft = eM.y;
-                    else Mleft = (gleft - gb_prev) + eT.x;                                   // PW:285-295
-                    const int P_in = needP ? (int)eP.x : PWR_BIG;
-                    if (x > 0 && !ran_prev) {
-#pragma unroll
-                        for (int i = 0; i < C; ++i) Mprev[i] = (rz[i] - gb_prev) + eT.x;
-                    }
-                    const unsigned pm1_0 = (unsigned)__builtin_amdgcn_update_dpp((int)Mleft, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
-                    int tg[C], grel[C];
-                    bool inb[C], lft[C], fcv[C], fav[C];
-                    int run = PWR_BIG;
-                    const int rel0 = y0 + lc - a;
-#pragma unroll
-                    for (int i = 0; i < C; ++i) {
-                        const int rel = rel0 + i;
-                        inb[i] = (unsigned)rel < (unsigned)Bx;
-                        lft[i] = rel < 0;
-                        grel[i] = (int)(rz[i] - gb);
-                        const unsigned pm = Mprev[i];
-                        const unsigned pm1 = i ? Mprev[i > 0 ? i - 1 : 0] : pm1_0;
-                        const unsigned sy = (((sx & 2) ? ry[i] : rx[i]) >> ((sx & 1) * 16)) & 0xffffu;
-                        const unsigned diag = pm1 + sy;                                      // PW:1503
-                        const unsigned up = pm + rw[i];                                     // PW:1507
-                        const unsigned t = min(min(diag, up), PWR_INF);
-                        fcv[i] = diag <= up;
-                        tg[i] = inb[i] ? (int)t - grel[i] : PWR_BIG;
-                        run = min(run, tg[i]);
-                    }
-                    const int incl = wave_incl_min(run);
-                    const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
-                    const int P_end = min(P_in, __builtin_amdgcn_readlane(incl, 63));
-                    int p = min(P_in, excl);
-                    unsigned Mn[C];
-#pragma unroll
-                    for (int i = 0; i < C; ++i) {
-                        fav[i] = tg[i] >= p;
-                        p = min(p, tg[i]);
-                        Mn[i] = lft[i] ? PWR_INF : (unsigned)(grel[i] + p);
-                    }
-                    if (x == L - 1) {
-                        // PW:1386: on the last row "M == M(x,y-1)" also moves left; keep the row for the entry scan
-                        const unsigned mrow = needP ? eP.y : PWR_INF;
-                        const unsigned left0 = (unsigned)__builtin_amdgcn_update_dpp((int)mrow, (int)Mn[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
-#pragma unroll
-                        for (int i = 0; i < C; ++i) {
-                            const unsigned lf = i ? Mn[i > 0 ? i - 1 : 0] : left0;
-                            fav[i] = fav[i] || (inb[i] && Mn[i] == lf);
-                            lastM[wave * MS + lc + i] = inb[i] ? Mn[i] : 0xffffffffu;
-                        }
-                    }
-#pragma unroll
-                    for (int i = 0; i < C; ++i) {
-                        Mprev[i] = Mn[i];
-                        accA[i] = (accA[i] << 1) | (fav[i] ? 1u : 0u);
-                        accC[i] = (accC[i] << 1) | (fcv[i] ? 1u : 0u);
-                    }
-                    if (lane == 63) {
-                        mb[wave][x & (LS_D - 1)] = make_uint4((unsigned)P_end, Mn[C - 1], (unsigned)(x + 1), 0u);
-                        if (ms == ms_hi) ptb[x & (LS_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)(x + 1));
-                    }
-                    if ((x & 15) == 15 || x == L - 1) {
-                        const int sh = 15 - (x & 15);
-                        uint32_t *d = dirs + (size_t)(x >> 4) * RS + (size_t)wave * MS + (size_t)lc;
-#pragma unroll
-                        for (int i = 0; i < C; ++i) {
-                            d[i] = ((accA[i] << sh) & 0xffffu) | (((accC[i] << sh) & 0xffffu) << 16);
-                            accA[i] = accC[i] = 0;
-                        }
-                    }
-                    ran_prev = true;
-                    a_prev = a; Bx_prev = Bx; gb_prev = gb;
-                    ++x;
-                    if (x == L) {
-                        finished = true;
-                        if (lane == 0) atomicAdd(&s_done, 1);
-                    } else {
-                        if ((x >> 6) != blk) {
-                            blk = x >> 6;
-                            wcur = wnxt; scur = snxt; gcur = gnxt;
-                            wnxt = way[min(x + 64 + lane, L - 1)];
-                            snxt = seq[min(x + 64 + lane, L - 1)];
-                            gnxt = gbase[min(x + 64 + lane, L - 1)];
-                        }
-                        a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
-                        gb = (unsigned)__builtin_amdgcn_readlane((int)gcur, x & 63);
-                        sx = __builtin_amdgcn_readlane(scur, x & 63);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= NW) break;
-    }
-    if (round >= max_rounds) {
-        if (tid == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
-        return;
-    }
-    if (tid == 0) {
-        m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
-        m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
-        m->rounds = round;
-        atomicAdd(&st.hdr->cells_computed, m->cells);
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// fill v2: the lock-step wave pipeline of k_fill_ls with the per-cell and per-row work cut down.
+// fill v2: the wave pipeline in lock-step rounds (one s_barrier per round instead of polled mailboxes),
+// with the per-cell and per-row work cut down.
 //   * prefix sums G are absolute (their total is the number of bases in the interval, < 2^29, checked by
 //     the gather), so the per-column constants S_b - G, up - G, INF - G are precomputed once per column
 //     and a candidate is  tg = min3(pm1 + (S_b - G), pm + (up - G), INF - G)  -- three VALU ops;
@@ -1147,7 +880,9 @@ template <int NW, int C>
 __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 {
     constexpr int MS = 64 * C, RS = NW * MS;
-    __shared__ uint4 mb[NW][V2_D];                  // {P_end, M_last, tag = row + 1, -}
+    __shared__ uint2 mbD[NW][V2_D];                 // {P_end, M_last} of row x in slot x % V2_D: one aligned 8-byte store
+    __shared__ int wseq[NW];                         // rows wave w is done with; stored after the row's mbD entry, and LDS
+                                                    // executes one wave's stores in order, so seq > x means entry x is there
     __shared__ uint2 ptb[V2_PD];                    // {Ptot, tag}
     __shared__ int s_done;
 
@@ -1157,7 +892,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     const int L = UNI(m->L);
     if (L <= 0 || !m->ok) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
-    for (int i = tid; i < NW * V2_D; i += NW * 64) (&mb[0][0])[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < NW * V2_D; i += NW * 64) (&mbD[0][0])[i] = make_uint2(0, 0);
+    if (tid < NW) wseq[tid] = 0;
     for (int i = tid; i < V2_PD; i += NW * 64) ptb[i] = make_uint2(0, 0);
     if (tid == 0) s_done = 0;
     __syncthreads();
@@ -1202,6 +938,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     {                                                                                            \
         a_prev = a; Bx_prev = Bx;                                                                \
         ++x;                                                                                     \
+        if (lane == 63) __hip_atomic_store(&wseq[wave], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
         if (x < L) {                                                                             \
             if ((x >> 6) != blk) {                                                               \
                 blk = x >> 6;                                                                    \
@@ -1233,12 +970,15 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
             //      The left neighbour's mailbox entry of the NEXT row is fetched while the current row is computed.
             bool not_ready = false;
             {
-                uint4 fP4 = mb[wl][x & (V2_D - 1)];
-                uint4 fM4 = mb[wl][(x - 1) & (V2_D - 1)];
+                int avail = UNI(__hip_atomic_load(&wseq[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                uint2 fD2 = mbD[wl][x & (V2_D - 1)];                    // {P_end(x), M_last(x)} of the left neighbour
+                unsigned mlast = UNI(mbD[wl][(x - 1) & (V2_D - 1)].y);  // M_last(x-1)
                 while (budget > 0) {
 #ifdef PWR_STAMPS
                     const unsigned long long f0 = __builtin_amdgcn_s_memtime();
 #endif
+                    x = UNI(x); a = UNI(a); a_prev = UNI(a_prev); Bx_prev = UNI(Bx_prev); sx = UNI(sx); budget = UNI(budget);
+                    avail = UNI(avail); mlast = UNI(mlast);
                     const int Bxf = min(B, W - a);
                     const int y0f = lo + ms * MS;
                     const bool simple = (a < y0f + MS) && (a + Bxf > y0f) && x > 0 && ran_prev && x < L - 1 &&
@@ -1248,31 +988,26 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                     const bool needPf = a < y0f;                                     // ms > ms_lo
                     const bool inMf = yqf >= a_prev && yqf < a_prev + Bx_prev;
                     const bool needTf = yqf >= a_prev + Bx_prev;
-                    unsigned fPx = UNI(fP4.x), fPy = UNI(fP4.y), fPz = UNI(fP4.z), fMy = UNI(fM4.y), fMz = UNI(fM4.z);
-                    unsigned fTx = 0;
-                    bool readyf = (!needPf || fPz == (unsigned)(x + 1)) && (!inMf || fMz == (unsigned)x);
-                    if (!readyf) {                                                   // the prefetched copy may be stale: look again
-                        fP4 = mb[wl][x & (V2_D - 1)];
-                        fM4 = mb[wl][(x - 1) & (V2_D - 1)];
-                        fPx = UNI(fP4.x); fPy = UNI(fP4.y); fPz = UNI(fP4.z); fMy = UNI(fM4.y); fMz = UNI(fM4.z);
-                        readyf = (!needPf || fPz == (unsigned)(x + 1)) && (!inMf || fMz == (unsigned)x);
+                    if (needPf && x >= avail) {                                      // look again: the neighbour may have moved on
+                        avail = UNI(__hip_atomic_load(&wseq[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                        fD2 = mbD[wl][x & (V2_D - 1)];
+                        if (x >= avail) { not_ready = true; break; }
                     }
-                    if (readyf && needTf) {
+                    unsigned fTx = 0;
+                    if (needTf) {
                         const uint2 fT2 = ptb[(x - 1) & (V2_PD - 1)];
                         fTx = UNI(fT2.x);
-                        readyf = UNI(fT2.y) == (unsigned)x;
+                        if (UNI(fT2.y) != (unsigned)x) { not_ready = true; break; }
                     }
-                    if (!readyf) { not_ready = true; break; }
+                    const unsigned fPx = UNI(fD2.x), fMx = UNI(fD2.y);
 #ifdef PWR_STAMPS
                     const unsigned long long f1 = __builtin_amdgcn_s_memtime();
 #endif
                     --budget;
-                    // next row's entry: this row's entry also carries M_last(x) = what row x+1 needs as M_last(x)
-                    fM4 = fP4;
-                    fP4 = mb[wl][(x + 1) & (V2_D - 1)];
-                    (void)fPy;
-                    const int Mleftf = inMf ? (int)fMy : (needTf ? gleft + (int)fTx : (int)PWR_INF);
+                    fD2 = mbD[wl][(x + 1) & (V2_D - 1)];                             // next row's entry, used only if seq allows
+                    const int Mleftf = inMf ? (int)mlast : (needTf ? gleft + (int)fTx : (int)PWR_INF);
                     const int P_inf = needPf ? (int)fPx : PWR_BIG;
+                    mlast = fMx;                                                     // valid whenever the next row needs it
                     const unsigned bit = 1u << (15 - (x & 15));
                     const int pm1_0 = __builtin_amdgcn_update_dpp(Mleftf, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
                     int t3[C];
@@ -1306,12 +1041,13 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                         p = min(p, tg[i]);
                         Mprev[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
                     }
-                    if (lane == 63) {
-                        mb[wave][x & (V2_D - 1)] = make_uint4((unsigned)P_end, Mprev[C - 1], (unsigned)(x + 1), 0u);
-                        if (a + Bxf <= y0f + MS) ptb[x & (V2_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)(x + 1));
-                    }
                     a_prev = a; Bx_prev = Bxf;
                     ++x;
+                    if (lane == 63) {
+                        mbD[wave][(x - 1) & (V2_D - 1)] = make_uint2((unsigned)P_end, Mprev[C - 1]);
+                        if (a + Bxf <= y0f + MS) ptb[(x - 1) & (V2_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)x);
+                        __hip_atomic_store(&wseq[wave], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
                     sx = __builtin_amdgcn_readlane(scur, x & 63);
 #ifdef PWR_STAMPS
@@ -1355,14 +1091,14 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
             const bool needP = ms > ms_lo;
             const bool needM = x > 0 && yq >= a_prev && yq < a_prev + Bx_prev;
             const bool needT = x > 0 && ((yq >= a_prev + Bx_prev) || !ran_prev);
-            const uint4 eP4 = mb[wl][x & (V2_D - 1)];
-            const uint4 eM4 = mb[wl][(x - 1) & (V2_D - 1)];
+            const int seqL = UNI(__hip_atomic_load(&wseq[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint2 eD2 = mbD[wl][x & (V2_D - 1)];                  // {P_end(x), M_last(x)} of the left neighbour
+            const uint2 eM2 = mbD[wl][(x - 1) & (V2_D - 1)];
             const uint2 eT2 = ptb[(x - 1) & (V2_PD - 1)];
-            const unsigned ePx = UNI(eP4.x), ePy = UNI(eP4.y), ePz = UNI(eP4.z);
-            const unsigned eMy = UNI(eM4.y), eMz = UNI(eM4.z);
+            const unsigned ePx = UNI(eD2.x), ePy = UNI(eD2.y);
+            const unsigned eMy = UNI(eM2.y);
             const unsigned eTx = UNI(eT2.x), eTy = UNI(eT2.y);
-            const bool ready = (!needP || ePz == (unsigned)(x + 1)) && (!needM || eMz == (unsigned)x) &&
-                               (!needT || eTy == (unsigned)x);
+            const bool ready = (!needP || x < seqL) && (!needM || x - 1 < seqL) && (!needT || eTy == (unsigned)x);
             if (!ready) break;
             --budget;
             int Mleft = (int)PWR_INF;
@@ -1426,7 +1162,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 }
             }
             if (lane == 63) {
-                mb[wave][x & (V2_D - 1)] = make_uint4((unsigned)P_end, Mprev[C - 1], (unsigned)(x + 1), 0u);
+                mbD[wave][x & (V2_D - 1)] = make_uint2((unsigned)P_end, Mprev[C - 1]);
                 if (ms == ms_hi) ptb[x & (V2_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)(x + 1));
             }
             ran_prev = 1;
@@ -1907,7 +1643,7 @@ struct pwr_ctx {
     int threads = 256;
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int fill_mode = 3;
-    int wp_waves = 5;                     // waves per DP of the v2 wave pipeline: 9/8/5/4/3 with 2/3/4/6/8 columns per lane                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 2: wave pipeline in lock-step rounds (k_fill_ls)
+    int wp_waves = 5;                     // waves per DP of the v2 wave pipeline: 9/8/5/4/3 with 2/3/4/6/8 columns per lane                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 3: wave pipeline in lock-step rounds (k_fill_v2)
     int cells_per_thread = 1;
     // stats
     pwr_stats stats{};
@@ -2238,7 +1974,8 @@ static int launch_fill(pwr_ctx *c, int njobs)
     const int NT = c->threads, C = c->cells_per_thread, NC = NT * C;
     const size_t lds = (size_t)4 * NC * 16 + (size_t)2 * NC * 4 + 16 * 4 + 64 * 4;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profile) {
+    const bool timed = c->profile && c->ev_used < (size_t)(1 << 16);      // beyond that the launches are sampled no further
+    if (timed) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;
             HIPC(hipEventCreate(&a)); HIPC(hipEventCreate(&b));
@@ -2255,9 +1992,6 @@ static int launch_fill(pwr_ctx *c, int njobs)
         else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v2<3, 8>), dim3(njobs), dim3(3 * 64), 0, c->stream, c->st, c->jb);
         else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v2<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_v2<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
-    } else if (c->fill_mode == 2) {
-        if (c->B <= 1024) hipLaunchKernelGGL((k_fill_ls<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
-        else hipLaunchKernelGGL((k_fill_ls<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
     } else if (c->fill_mode == 1) {
         if (c->B <= 1024) hipLaunchKernelGGL((k_fill_wp<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_wp<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
@@ -2274,7 +2008,7 @@ static int launch_fill(pwr_ctx *c, int njobs)
     else if (NT == 512 && C == 4) hipLaunchKernelGGL((k_fill<512, 4>), dim3(njobs), dim3(512), lds, c->stream, c->st, c->jb);
     else return PWR_ERR_ARG;
     HIPC(hipGetLastError());
-    if (c->profile) HIPC(hipEventRecord(e1, c->stream));
+    if (timed) { HIPC(hipEventRecord(e1, c->stream)); c->stats.fill_launches_timed += 1; }
     c->stats.fill_launches += 1;
     return PWR_OK;
 }
@@ -2341,7 +2075,6 @@ static int check_status(pwr_ctx *c)
     c->stats.cells_reference = h.cells_reference;
     c->stats.rows_changed = h.rows_changed;
     for (int i = 0; i < 4; ++i) c->stats.reject_reason[i] = h.fail_reason[i];
-    if ((rc = drain_events(c))) return rc;
     return h.status;
 }
 
@@ -2374,7 +2107,6 @@ static int run_batch(pwr_ctx *c, int k0, int n, int *done)
         if (c->rowlen[k] == 0) continue;
         if (k < k0 + h.ncommitted) c->stats.rows_committed += 1; else c->stats.rows_recomputed += 1;
     }
-    if (c->profile && c->ev_used >= 1024) rc = drain_events(c);
     return rc;
 }
 
@@ -2398,8 +2130,12 @@ extern "C" int pwr_realign_round(pwr_ctx *c)
     while (k < c->T) {
         // A batch costs as long as its longest fill; rows that overlap the rows before them are almost
         // always invalidated while the MSA is still moving, so speculate just past the running mean.
-        int n = (int)(ema + 1.6);
+        int n = (int)(ema + 2.6);
         n = std::max(1, std::min(n, std::min(c->window, c->T - k)));
+        // ... and never let a speculative row make the batch longer than its first row, the only one
+        // that is certain to commit: a fill takes time proportional to the row's length
+        for (int j = 1; j < n; ++j)
+            if (c->rowlen[k + j] > c->rowlen[k] + c->rowlen[k] / 16 + 64) { n = j; break; }
         int done = 0;
         if ((rc = run_batch(c, k, n, &done))) return rc;
         ema = 0.75 * ema + 0.25 * done;
@@ -2499,7 +2235,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!c || !key) return PWR_ERR_ARG;
     if (!strcmp(key, "window")) { if (value < 1 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
-    if (!strcmp(key, "fill")) { if (c->on_device || value < 0 || value > 3) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
+    if (!strcmp(key, "fill")) { if (c->on_device || (value != 0 && value != 1 && value != 3)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
     if (!strcmp(key, "threads")) {
@@ -2517,6 +2253,7 @@ extern "C" int pwr_get_stats(pwr_ctx *c, pwr_stats *out)
         if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
         int rc = check_status(c);
         if (rc) return rc;
+        if ((rc = drain_events(c))) return rc;      // HIP-event durations are read here, outside any timed region
     }
     *out = c->stats;
     return PWR_OK;
@@ -2525,6 +2262,11 @@ extern "C" int pwr_get_stats(pwr_ctx *c, pwr_stats *out)
 extern "C" int pwr_reset_stats(pwr_ctx *c)
 {
     if (!c) return PWR_ERR_ARG;
+    if (c->on_device) {
+        if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+        int rc0 = drain_events(c);
+        if (rc0) return rc0;
+    }
     c->stats = pwr_stats{};
     if (c->on_device) {
         if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;

@@ -33,7 +33,7 @@ STEP_CASES = [("toy_a_b1000", 1000, 2), ("toy_a_b50", 50, 2), ("tiny_b10", 10, 3
               ("lowcov_b300", 300, 3), ("edge_shift", 12, 2), ("deep_b200", 200, 1)]
 
 
-@pytest.mark.parametrize("fill", [3, 2, 1, 0], ids=["v2", "lockstep", "wavepipe", "ldsfill"])
+@pytest.mark.parametrize("fill", [3, 1, 0], ids=["v2", "wavepipe", "ldsfill"])
 @pytest.mark.parametrize("name,bw,rounds", STEP_CASES, ids=[c[0] for c in STEP_CASES])
 def test_row_by_row_against_oracle(name, bw, rounds, fill, oracle):
     """Every single realignment: same Way, same entry column, same new placement, same MSA."""
@@ -70,7 +70,7 @@ def test_row_by_row_against_oracle(name, bw, rounds, fill, oracle):
     g.close()
 
 
-@pytest.mark.parametrize("fill", [3, 2, 1, 0], ids=["v2", "lockstep", "wavepipe", "ldsfill"])
+@pytest.mark.parametrize("fill", [3, 1, 0], ids=["v2", "wavepipe", "ldsfill"])
 @pytest.mark.parametrize("window", [1, 3, 64])
 def test_batched_rounds_match_sequential_oracle(window, fill, oracle):
     """Speculative batches of any size must give the row-sequential result (commit in row order,
