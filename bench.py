@@ -24,6 +24,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_CELL = 4.0           # algorithmic bytes per DP cell (one 32-bit score per cell)
 
 
+def measured_traffic_per_cell():
+    """HBM bytes per computed DP cell of the fill kernel, from the committed rocprofv3 PMC passes
+    (profiles/r01_traffic_model.json: 2 x FETCH_SIZE + WRITE_SIZE over the cells of the same run)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic_model.json")) as f:
+            return float(json.load(f)["hbm_bytes_per_cell"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(rows, bandwidth, budget_s=15.0):
     """oracle/ is the checker; here it is only timed (kind "port", 1 core) on a bounded sample:
     the first rows of round 1 of the same MSA, until budget_s of CPU time is used."""
@@ -68,6 +78,8 @@ def main():
     ap.add_argument("--waves", type=int, default=None, help="waves per DP of the v2 fill (9 or 5)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
     args = ap.parse_args()
 
     import torch
@@ -75,10 +87,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    dev = 0 if args.one_device else local_rank
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank if torch.cuda.is_available() else 0
+        torch.cuda.set_device(dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.backend)
+    red_dev = "cuda" if (world > 1 and args.backend == "nccl") else "cpu"
 
     from repeatresolver_amd import datagen as dg
     from repeatresolver_amd.realigner import PWReAligner
@@ -128,9 +144,9 @@ def main():
     cells = float(st["cells_reference"])
     tmax, csum = dt, cells
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        cs = torch.tensor([cells], dtype=torch.float64, device="cuda")
+        cs = torch.tensor([cells], dtype=torch.float64, device=red_dev)
         dist.all_reduce(cs, op=dist.ReduceOp.SUM)
         tmax, csum = float(t.item()), float(cs.item())
 
@@ -163,8 +179,13 @@ def main():
                        "fill_threads": args.threads, "shader_clock_mhz_last_fill": round(clk_mhz),
                        "generate_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_fill", "launches": st["fill_launches"],
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (None if measured_traffic_per_cell() is None
+                                     else measured_traffic_per_cell() * st["cells_computed"] / launches),
+                         "traffic_unit": "HBM bytes per launch = PMC-measured bytes per cell (profiles/r01_traffic_model.json) "
+                                         "x cells of the average launch",
+                         "algorithmic_bytes_per_launch": BYTES_PER_CELL * st["cells_computed"] / launches,
+                         "kernel": "k_fill_v2", "launches": st["fill_launches"],
                          "avg_launch_ms": st["fill_ms"] / timed,
                          "cells_per_launch": st["cells_computed"] / launches,
                          "note": "achieved = cells computed by k_fill x 4 B / sum of HIP-event launch durations"},

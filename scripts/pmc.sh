@@ -1,11 +1,11 @@
 #!/bin/bash
-# PMC passes for the fill kernel (dev tool). usage: pmc.sh <workload> <fill> "<counters>" <tag>
-WL=$1; FILL=$2; CNT=$3; TAG=$4
+# PMC passes for the fill kernel (dev tool). usage: pmc.sh <workload> "<counters>" <tag>
+WL=$1; CNT=$2; TAG=$3
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/pmc_$TAG
-timeout -k 10 400 rocprofv3 --pmc $CNT --output-format csv -d gpurun_out/pmc_$TAG -- python bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline --fill $FILL --window 1 > gpurun_out/pmc_$TAG.json 2> gpurun_out/pmc_$TAG.err
+timeout -k 10 500 rocprofv3 --pmc $CNT --output-format csv -d gpurun_out/pmc_$TAG -- python bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline --window 1 > gpurun_out/pmc_$TAG.json 2> gpurun_out/pmc_$TAG.err
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, json
 f = glob.glob("gpurun_out/pmc_$TAG/*/*counter_collection.csv")
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for fn in f:
@@ -13,7 +13,10 @@ for fn in f:
         k = r["Kernel_Name"].split("(")[0][:40]
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         n[(k, r["Counter_Name"])] += 1
+out = {}
 for k in agg:
-    if "fill" in k or "trace" in k or "commit" in k:
-        print(k, {c: "%.4g" % v for c, v in agg[k].items()}, "dispatches", max(n[(k, c)] for c in agg[k]))
+    out[k] = {c: v for c, v in agg[k].items()}
+    out[k]["dispatches"] = max(n[(k, c)] for c in agg[k])
+    print(k, {c: "%.4g" % v for c, v in agg[k].items()}, "dispatches", out[k]["dispatches"])
+json.dump(out, open("gpurun_out/pmc_$TAG.summary.json", "w"), indent=1)
 PY
