@@ -88,6 +88,8 @@ struct JobBufs {
     int *newcol;                   // [njobs][Lmax]   (ordinal << 1) | opened-a-new-column
     int *aux;                      // [njobs][Lmax]   slot of every base after the commit
     unsigned *gbase;               // [njobs][Lmax]   G(anf(x)): per-DP-row base of the prefix sums
+    uint4 *desc;                   // [njobs][Lmax]   per DP row: {anf, Bx | base << 16, wave flags 0-7, wave flags 8-15} (k_fill_v2)
+    int wpNW, wpMS;                // geometry of the wave pipeline the descriptors are made for
     unsigned *lastM;               // [njobs][NC]     scores of the last DP row (wave-pipeline fill)
     int layout;                    // 0: dirs indexed by band cell (y - anf(x)); 1: by (y - lo) mod NC
     int Lmax, colcap, NC;
@@ -268,6 +270,37 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
             const int ax = max(0, way[x] - H);
             gbase[x] = rec[ax - lo].z;
             mycells += (unsigned long long)min(B, W - ax);                  // cells of DP row x, PW:1496-1499
+        }
+    }
+    if (jb.wpNW > 0) {
+        // Row descriptors for k_fill_v2: what every wave would otherwise recompute per DP row.  Wave w owns the
+        // macro-strip ms = ms_lo + ((w - ms_lo) mod NW) in row x; 4 flag bits per wave:
+        //   bit0 "ordinary row": the wave has work in rows x-1 and x on the same macro-strip, 0 < x < L-1
+        //   bit1 needs the left neighbour's running minimum (its macro-strip is not the band's first)
+        //   bits2-3 where the score left of the macro-strip comes from: 0 = INF (PW:276), 1 = the neighbour's
+        //           boundary score of row x-1, 2 = virtual extension G + Ptot(x-1) (PW:285-295)
+        uint4 *desc = jb.desc + (size_t)job * jb.Lmax;
+        const int NWg = jb.wpNW, MSg = jb.wpMS;
+        for (int x = tid; x < L; x += GATHER_NT) {
+            const int ax = max(0, way[x] - H), bx = min(B, W - ax);
+            const int mlo = (ax - lo) / MSg, mhi = (ax + bx - 1 - lo) / MSg;
+            int ap = 0, bp = 0, plo = 0, phi = -1;
+            if (x > 0) {
+                ap = max(0, way[x - 1] - H); bp = min(B, W - ap);
+                plo = (ap - lo) / MSg; phi = (ap + bp - 1 - lo) / MSg;
+            }
+            unsigned long long fl = 0;
+            for (int w = 0; w < NWg; ++w) {
+                const int msw = mlo + (((w - mlo) % NWg) + NWg) % NWg;
+                if (msw > mhi) continue;
+                const int msp = plo + (((w - plo) % NWg) + NWg) % NWg;
+                const bool ranp = x > 0 && msp == msw && msp <= phi;
+                const int yq = lo + msw * MSg - 1;
+                const unsigned kind = (x == 0 || yq < ap) ? 0u : (yq < ap + bp ? 1u : 2u);
+                const unsigned bits = ((ranp && x < L - 1) ? 1u : 0u) | (msw > mlo ? 2u : 0u) | (kind << 2);
+                fl |= (unsigned long long)bits << (4 * w);
+            }
+            desc[x] = make_uint4((unsigned)ax, (unsigned)bx | ((unsigned)st.seq[off + x] << 16), (unsigned)fl, (unsigned)(fl >> 32));
         }
     }
     for (int o = 32; o > 0; o >>= 1) mycells += __shfl_xor(mycells, o);
@@ -923,6 +956,13 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     int x = 0, blk = 0;
     int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
     int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
+    // row descriptors of the gather (64 rows per register, like Way[]): anf, Bx | base << 16, this wave's flags
+    const uint4 *desc = jb.desc + (size_t)job * jb.Lmax;
+    const int fsh = 4 * (wave & 7);
+    uint4 d4 = desc[min(lane, L - 1)];
+    unsigned dca = d4.x, dcb = d4.y, dcf = (wave < 8 ? d4.z : d4.w) >> fsh;
+    d4 = desc[min(64 + lane, L - 1)];
+    unsigned dna = d4.x, dnb = d4.y, dnf = (wave < 8 ? d4.z : d4.w) >> fsh;
     int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H), a_prev = 0, Bx_prev = 0;
     int sx = __builtin_amdgcn_readlane(scur, 0);
     const int max_rounds = 4 * L + 64 * NW + 1024;
@@ -942,9 +982,11 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
         if (x < L) {                                                                             \
             if ((x >> 6) != blk) {                                                               \
                 blk = x >> 6;                                                                    \
-                wcur = wnxt; scur = snxt;                                                        \
+                wcur = wnxt; scur = snxt; dca = dna; dcb = dnb; dcf = dnf;                       \
                 wnxt = way[min(x + 64 + lane, L - 1)];                                           \
                 snxt = seq[min(x + 64 + lane, L - 1)];                                           \
+                { const uint4 e4_ = desc[min(x + 64 + lane, L - 1)];                             \
+                  dna = e4_.x; dnb = e4_.y; dnf = (wave < 8 ? e4_.z : e4_.w) >> fsh; }           \
             }                                                                                    \
             a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);                             \
             sx = __builtin_amdgcn_readlane(scur, x & 63);                                        \
@@ -969,32 +1011,34 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
             //      16-row group and 64-row block, previous row done by this wave) as straight-line code.
             //      The left neighbour's mailbox entry of the NEXT row is fetched while the current row is computed.
             bool not_ready = false;
-            {
+            if ((x >> 4) == gacc) {
                 int avail = UNI(__hip_atomic_load(&wseq[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 uint2 fD2 = mbD[wl][x & (V2_D - 1)];                    // {P_end(x), M_last(x)} of the left neighbour
                 unsigned mlast = UNI(mbD[wl][(x - 1) & (V2_D - 1)].y);  // M_last(x-1)
-                while (budget > 0) {
+                const int y0f = lo + ms * MS;
+                const int rel00 = y0f + lc;
+                // rows this loop may take: same 16-row group, row x+1 in the same 64-row block, not the last row
+                const int xstop = min(min(L - 1, ((x >> 4) + 1) << 4), ((blk + 1) << 6) - 1);
+                const int x_in = x;
+                while (budget > 0 && x < xstop) {
 #ifdef PWR_STAMPS
                     const unsigned long long f0 = __builtin_amdgcn_s_memtime();
 #endif
-                    x = UNI(x); a = UNI(a); a_prev = UNI(a_prev); Bx_prev = UNI(Bx_prev); sx = UNI(sx); budget = UNI(budget);
-                    avail = UNI(avail); mlast = UNI(mlast);
-                    const int Bxf = min(B, W - a);
-                    const int y0f = lo + ms * MS;
-                    const bool simple = (a < y0f + MS) && (a + Bxf > y0f) && x > 0 && ran_prev && x < L - 1 &&
-                                        (x >> 4) == gacc && ((x + 1) >> 6) == blk;
-                    if (!simple) break;
-                    const int yqf = y0f - 1;
-                    const bool needPf = a < y0f;                                     // ms > ms_lo
-                    const bool inMf = yqf >= a_prev && yqf < a_prev + Bx_prev;
-                    const bool needTf = yqf >= a_prev + Bx_prev;
+                    x = UNI(x); budget = UNI(budget); avail = UNI(avail); mlast = UNI(mlast);
+                    const unsigned fl = (unsigned)__builtin_amdgcn_readlane((int)dcf, x & 63) & 15u;
+                    if (!(fl & 1u)) break;                                           // not an ordinary row: general path
+                    const int af = __builtin_amdgcn_readlane((int)dca, x & 63);
+                    const unsigned db = (unsigned)__builtin_amdgcn_readlane((int)dcb, x & 63);
+                    const int Bxf = (int)(db & 0xffffu), sxf = (int)(db >> 16);
+                    const bool needPf = (fl & 2u) != 0;
+                    const unsigned kind = fl >> 2;
                     if (needPf && x >= avail) {                                      // look again: the neighbour may have moved on
                         avail = UNI(__hip_atomic_load(&wseq[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                         fD2 = mbD[wl][x & (V2_D - 1)];
                         if (x >= avail) { not_ready = true; break; }
                     }
                     unsigned fTx = 0;
-                    if (needTf) {
+                    if (kind == 2u) {
                         const uint2 fT2 = ptb[(x - 1) & (V2_PD - 1)];
                         fTx = UNI(fT2.x);
                         if (UNI(fT2.y) != (unsigned)x) { not_ready = true; break; }
@@ -1005,13 +1049,13 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 #endif
                     --budget;
                     fD2 = mbD[wl][(x + 1) & (V2_D - 1)];                             // next row's entry, used only if seq allows
-                    const int Mleftf = inMf ? (int)mlast : (needTf ? gleft + (int)fTx : (int)PWR_INF);
+                    const int Mleftf = kind == 1u ? (int)mlast : (kind == 2u ? gleft + (int)fTx : (int)PWR_INF);
                     const int P_inf = needPf ? (int)fPx : PWR_BIG;
                     mlast = fMx;                                                     // valid whenever the next row needs it
                     const unsigned bit = 1u << (15 - (x & 15));
                     const int pm1_0 = __builtin_amdgcn_update_dpp(Mleftf, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
                     int t3[C];
-                    switch (sx) {
+                    switch (sxf) {
                     case 0: V2_CASE(sg0) break;
                     case 1: V2_CASE(sg1) break;
                     case 2: V2_CASE(sg2) break;
@@ -1020,7 +1064,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 #ifdef PWR_STAMPS
                     const unsigned long long f2 = __builtin_amdgcn_s_memtime();
 #endif
-                    const int rel0 = y0f + lc - a;
+                    const int rel0 = rel00 - af;
                     int tg[C];
                     int run = PWR_BIG;
 #pragma unroll
@@ -1041,18 +1085,21 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                         p = min(p, tg[i]);
                         Mprev[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
                     }
-                    a_prev = a; Bx_prev = Bxf;
                     ++x;
                     if (lane == 63) {
                         mbD[wave][(x - 1) & (V2_D - 1)] = make_uint2((unsigned)P_end, Mprev[C - 1]);
-                        if (a + Bxf <= y0f + MS) ptb[(x - 1) & (V2_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)x);
+                        if (af + Bxf <= y0f + MS) ptb[(x - 1) & (V2_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)x);
                         __hip_atomic_store(&wseq[wave], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
-                    a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
-                    sx = __builtin_amdgcn_readlane(scur, x & 63);
 #ifdef PWR_STAMPS
                     { const unsigned long long f4 = __builtin_amdgcn_s_memtime(); fs0 += f1 - f0; fs1 += f2 - f1; fs2 += f3 - f2; fs3 += f4 - f3; ++fsn; }
 #endif
+                }
+                if (x != x_in) {                                                     // resynchronise the general path's row state
+                    const int apw = __builtin_amdgcn_readlane(wcur, (x - 1) & 63);
+                    a_prev = max(0, apw - H); Bx_prev = min(B, W - a_prev);
+                    a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+                    sx = __builtin_amdgcn_readlane(scur, x & 63);
                 }
             }
             if (not_ready || budget <= 0) break;
@@ -1649,6 +1696,7 @@ struct pwr_ctx {
     pwr_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
+    void *h_hdr = nullptr;                // pinned staging buffer for the device header
     // all device allocations, for cleanup
     std::vector<void *> allocs;
 };
@@ -1715,6 +1763,7 @@ static void free_device(pwr_ctx *c)
     c->ev_pool.clear();
     c->ev_used = 0;
     if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
+    if (c->h_hdr) { (void)hipHostFree(c->h_hdr); c->h_hdr = nullptr; }
     c->on_device = false;
 }
 
@@ -1801,6 +1850,9 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     if ((rc = dmalloc(c, &jb.newcol, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.aux, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.gbase, (size_t)njobs * jb.Lmax))) return rc;
+    if ((rc = dmalloc(c, &jb.desc, (size_t)njobs * jb.Lmax))) return rc;
+    jb.wpNW = c->fill_mode == 3 ? c->wp_waves : 0;
+    jb.wpMS = 64 * wpC;
     if ((rc = dmalloc(c, &jb.lastM, (size_t)njobs * jb.NC))) return rc;
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
     if (hipMemset(jb.meta, 0, sizeof(JobMeta) * njobs) != hipSuccess) return PWR_ERR_DEVICE;
@@ -1812,7 +1864,7 @@ static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
     dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.rec); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
-    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.lastM); dfree(c, c->d_jobrows);
+    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -1921,8 +1973,15 @@ static int upload(pwr_ctx *c)
 
 static int read_hdr(pwr_ctx *c, Hdr *h)
 {
+    // one async copy into pinned memory + one stream wait: the only host round trip of a batch
+    if (!c->h_hdr) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, sizeof(Hdr), hipHostMallocDefault) != hipSuccess) return PWR_ERR_NOMEM;
+        c->h_hdr = p;
+    }
+    HIPC(hipMemcpyAsync(c->h_hdr, c->st.hdr, sizeof(Hdr), hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    HIPC(hipMemcpy(h, c->st.hdr, sizeof(Hdr), hipMemcpyDeviceToHost));
+    memcpy(h, c->h_hdr, sizeof(Hdr));
     return PWR_OK;
 }
 
