@@ -884,6 +884,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_wp(DState st, JobBufs jb)
 #define V2_D 32
 #define V2_PD 64
 #define V2_R 8
+#define V2_SPINS 48
 #define UNI(v) __builtin_amdgcn_readfirstlane(v)
 
 #define V2_CASE(SGARR)                                                                           \
@@ -1032,10 +1033,16 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                     const int Bxf = (int)(db & 0xffffu), sxf = (int)(db >> 16);
                     const bool needPf = (fl & 2u) != 0;
                     const unsigned kind = fl >> 2;
-                    if (needPf && x >= avail) {                                      // look again: the neighbour may have moved on
-                        avail = UNI(__hip_atomic_load(&wseq[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                        fD2 = mbD[wl][x & (V2_D - 1)];
+                    if (needPf && x >= avail) {
+                        // the neighbour has not posted row x yet: wait for it a little (it is usually a few hundred
+                        // cycles away) before giving the round up; bounded, the barrier below is the fallback
+                        for (int spin = 0; spin < V2_SPINS; ++spin) {
+                            avail = UNI(__hip_atomic_load(&wseq[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                            if (x < avail) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
                         if (x >= avail) { not_ready = true; break; }
+                        fD2 = mbD[wl][x & (V2_D - 1)];
                     }
                     unsigned fTx = 0;
                     if (kind == 2u) {

@@ -50,9 +50,13 @@ def _allgather_bytes(payload: bytes, device):
     return [bytes(b[:int(s.item())].cpu().numpy().tobytes()) for b, s in zip(bufs, sizes)]
 
 
-def realign_sections(sections, bandwidth=1000, max_rounds=-1, worker=None, device=None):
+def realign_sections(sections, bandwidth=1000, max_rounds=-1, worker=None, device=None, concurrent=4):
     """sections: list (same on every rank) of sections, each a list of T rows.  Section p is realigned
-    by rank p % world.  Returns the realigned sections in order, identical on every rank."""
+    by rank p % world.  Returns the realigned sections in order, identical on every rank.
+
+    One realignment keeps only a handful of CUs busy (it is a chain of dependent DP rows), so a rank
+    runs up to `concurrent` of its sections side by side, each in its own context / HIP stream (the C
+    calls release the GIL)."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     use_cuda = dist.is_initialized() and dist.get_backend() == "nccl"
@@ -60,9 +64,16 @@ def realign_sections(sections, bandwidth=1000, max_rounds=-1, worker=None, devic
         device = torch.cuda.current_device() if (use_cuda or (not dist.is_initialized() and torch.cuda.is_available())) else 0
     worker = worker or gpu_realign_section
     mine = {}
-    for p in range(rank, len(sections), world):
-        out, _ = worker(sections[p], bandwidth, device, max_rounds)
-        mine[p] = out
+    my_ids = list(range(rank, len(sections), world))
+    if concurrent > 1 and len(my_ids) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(concurrent, len(my_ids))) as pool:
+            futs = {p: pool.submit(worker, sections[p], bandwidth, device, max_rounds) for p in my_ids}
+            for p, f in futs.items():
+                mine[p] = f.result()[0]
+    else:
+        for p in my_ids:
+            mine[p] = worker(sections[p], bandwidth, device, max_rounds)[0]
     if world == 1:
         return [mine[p] for p in range(len(sections))]
     # one message per rank: sections joined as  <p>\n<T>\n<row>\n...  records

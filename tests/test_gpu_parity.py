@@ -136,7 +136,8 @@ def test_sections_on_gpu(oracle):
     rows = split_rows(golden_input("toy_a_b1000"))
     W = len(rows[0])
     secs = slice_sections(rows, [0, W // 3, 2 * W // 3, W])
-    got = realign_sections(secs, bandwidth=200, max_rounds=2)
+    got = realign_sections(secs, bandwidth=200, max_rounds=2)          # the three sections run concurrently
+    assert got == realign_sections(secs, bandwidth=200, max_rounds=2, concurrent=1)
     for p, sec in enumerate(secs):
         exp, _ = _oracle_worker(sec, 200, 0, 2)
         assert got[p] == exp
@@ -206,3 +207,42 @@ def test_rows_without_bases_and_unsupported_states():
         g.realign_round()
     assert e.value.code == -7
     g.close()
+
+
+def test_medium_properties_and_kernel_cross_check():
+    """A shape too large for the oracle to follow row by row in the test budget (2.3 k rows x 37 k
+    columns, 8*10^9 cells per round): size-independent properties, and the three fill kernels and two
+    batch sizes against each other."""
+    import numpy as np
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    rows = [bytes(r) for r in dg.make_msa("tree_medium")]
+    ref = None
+    for fill, window in ((3, 8), (3, 1), (1, 4)):
+        g = PWReAligner(rows, bandwidth=1000, fill=fill, window=window)
+        g.trim_ends()
+        before = [r.replace(b"-", b"").replace(b" ", b"") for r in g.export_rows()]
+        s0 = g.total_score()
+        g.realign_round()
+        s1 = g.total_score()
+        out = g.export_rows()
+        st = g.stats()
+        g.close()
+        assert s1 < s0
+        assert [r.replace(b"-", b"").replace(b" ", b"") for r in out] == before          # bases and their order
+        m = np.frombuffer(b"".join(out), dtype=np.uint8).reshape(len(out), -1)
+        cov = (m != 0x20).sum(0).astype(np.int64)
+        tot = 0
+        for ch in b"ACGT-":                                                             # recount of PW:864-892
+            nb = (m == ch).sum(0).astype(np.int64)
+            tot += int((nb * (cov - nb)).sum())
+        assert tot == s1
+        assert (np.isin(m, list(b"ACGT")).sum(0) > 0).all()                             # no base-less column left
+        for r in out[::97]:
+            core = r.strip(b" ")
+            assert b" " not in core and core[:1] != b"-" and core[-1:] != b"-"
+        assert st["rows_committed"] == sum(1 for b in before if b)
+        if ref is None:
+            ref = (s1, out, st["cells_reference"])
+        else:
+            assert (s1, out, st["cells_reference"]) == ref
