@@ -118,9 +118,26 @@ def main():
     score0 = g.total_score()            # first device call: uploads the MSA into HBM
     note(f"resident in HBM, score {score0}")
     for i in range(args.warmup):
-        g.realign_round()
+        run_round(f"warm-up round {i + 1}")
         note(f"warm-up round {i + 1} done")
     g.reset_stats()
+
+    def run_round(tag):
+        """One realignment round with a heartbeat on stderr (a full-size round runs for minutes)."""
+        import threading
+        done = threading.Event()
+
+        def beat():
+            t_start = time.time()
+            while not done.wait(60.0):
+                note(f"{tag}: still running, {time.time() - t_start:.0f} s")
+        th = threading.Thread(target=beat, daemon=True)
+        th.start()
+        try:
+            g.realign_round()
+        finally:
+            done.set()
+            th.join()
 
     def fence():
         if world > 1:
@@ -130,7 +147,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        g.realign_round()
+        run_round(f"timed round {i + 1}")
         note(f"timed round {i + 1} done")
     fence()
     dt = time.perf_counter() - t0

@@ -228,6 +228,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     for (int x = tid; x < L; x += GATHER_NT) mark[way[x] - lo] = (uint8_t)(st.seq[off + x] + 1);
     __syncthreads();
     unsigned carry = 0, maxS = 0;
+    unsigned long long ucost = 0;                           // cost of the row where it stands now: an upper bound of the optimum
     if (tid == 0) s_cov[0] = 0;
     for (int base = 0; base < n; base += GATHER_NT) {
         const int i = base + tid;
@@ -243,6 +244,8 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
                 const int own = mk ? mk - 1 : 4;
 #pragma unroll
                 for (int b = 0; b < 6; ++b) w[b] -= (b != own) ? 1u : 0u;
+#pragma unroll
+                for (int b = 0; b < 5; ++b) ucost += (b == own) ? w[b] : 0u;
             }
         }
         unsigned tot;
@@ -307,12 +310,18 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     __shared__ unsigned long long s_cells[GATHER_NT / 64];
     if ((tid & 63) == 0) s_cells[tid >> 6] = mycells;
     __syncthreads();
-    // 32-bit DP range: every finite score is at most (L + columns) * maxS (one step per base or
-    // column, each costing at most maxS); unreachable cells are >= PWR_INF; prefix-sum offsets
-    // inside one DP row add at most (B + lookahead) * maxS.
     const unsigned mx = (unsigned)(~block_min_u32<GATHER_NT>(~maxS, sh));
+    for (int o = 32; o > 0; o >>= 1) ucost += __shfl_xor(ucost, o);
+    __shared__ unsigned long long s_u[GATHER_NT / 64];
+    if ((tid & 63) == 0) s_u[tid >> 6] = ucost;
+    __syncthreads();
     if (tid == 0) {
-        const unsigned long long bound = (unsigned long long)mx * (unsigned long long)(L + n + 2 * B + 4096);
+        // 32-bit range.  The row's present placement is a path inside the band, so the optimum and every
+        // cell on an optimal path are <= U = its cost; larger values may saturate at PWR_INF without
+        // touching any test the traceback makes.  Offsets of at most (2B + slack) * maxS are added on top.
+        unsigned long long U = 0;
+        for (int w = 0; w < GATHER_NT / 64; ++w) U += s_u[w];
+        const unsigned long long bound = U + (unsigned long long)mx * (unsigned long long)(2 * B + 4096);
         m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx;
         unsigned long long cs = 0;
         for (int w = 0; w < GATHER_NT / 64; ++w) cs += s_cells[w];
