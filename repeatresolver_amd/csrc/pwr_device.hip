@@ -1400,6 +1400,241 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
 }
 
 // ---------------------------------------------------------------------------------------------
+// trace, speculative-parallel form.  The traceback is a chain of L dependent steps, but its state
+// between two DP rows is only the column the trace arrives at.  TRK waves each take a chunk of rows:
+//   phase 0 (all waves at once): the top chunk starts from the true entry column; every other wave
+//     GUESSES its arrival column (where the row above used to sit) and traces its chunk from there,
+//     recording per row the arrival column and the placement;
+//   phase 1 (top-down hand-over): when the chunk above is final its true exit column is known; if
+//     the guess was right the chunk is final as it stands, otherwise the wave retraces from the true
+//     column until it arrives at a row in the same column as the guess did -- from there on the
+//     recorded steps are exactly the steps the true trace would make.  Optimal paths from nearby
+//     columns merge within a few rows, so the hand-over chain is short.
+// Results are those of k_trace_wp bit for bit (same per-row step; a step is a function of (row, column)).
+// ---------------------------------------------------------------------------------------------
+#define TRK 8
+#define TR_SPIN_LIMIT (1 << 22)
+__global__ __launch_bounds__(TRK * 64) void k_trace_par(DState st, JobBufs jb)
+{
+    __shared__ int s_yexit[TRK], s_cnt[TRK];
+    __shared__ int s_flag[TRK];                             // 1 = chunk final, 2 = error
+    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wv = UNI(tid >> 6);
+    JobMeta *m = &jb.meta[job];
+    const int L = UNI(m->L);
+    if (L <= 0 || !m->ok) return;
+    if (tid < TRK) { s_flag[tid] = 0; s_cnt[tid] = 0; s_yexit[tid] = 0; }
+    __syncthreads();
+    const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+    const unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
+    int *newcol = jb.newcol + (size_t)job * jb.Lmax;
+    int *yin = jb.aux + (size_t)job * jb.Lmax;             // arrival column per row (aux is rewritten by the commit later)
+
+    const int Lc = ((((L + TRK - 1) / TRK) + 63) >> 6) << 6;   // rows per chunk, a multiple of 64
+    const int nch = (L + Lc - 1) / Lc;                      // chunks in use; chunk nch-1 holds the last DP row
+    if (wv >= nch) return;
+    const int x_lo = wv * Lc, x_top = min(L, x_lo + Lc) - 1;
+    const bool top = (wv == nch - 1);
+
+    int yguess = 0, yout_guess = 0, xrec_lo = x_top + 1;    // rows [xrec_lo, x_top] were recorded in phase 0
+    int cnt = 0;                                            // 'up' moves (new columns) of the chunk as it stands
+    int err = 0;
+    for (int phase = 0; phase < 2; ++phase) {
+        int x = x_top, y;
+        bool check_merge = false;
+        if (phase == 0) {
+            if (top) {
+                // entry: minimum of the last row over y in [ylow, W-1], ties -> largest y; columns past the
+                // band carry the value of the last band cell (PW:287)
+                const int wx = way[x];
+                const int a = max(0, wx - H), Bx = min(B, W - a);
+                int ylow = max(-1, wx - H) + 1;
+                if (ylow > W - 1) ylow = W - 1;
+                unsigned long long key = ~0ull;
+                for (int yy = max(ylow, a) + lane; yy < a + Bx; yy += 64) {
+                    const unsigned v = lastM[(yy - lo) % RS];
+                    const unsigned long long k2 = ((unsigned long long)v << 32) | (unsigned)(~(unsigned)yy);
+                    key = k2 < key ? k2 : key;
+                }
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned long long other = __shfl_xor(key, o);
+                    key = other < key ? other : key;
+                }
+                const unsigned vmin = (unsigned)(key >> 32);
+                int entry = (key == ~0ull) ? -1 : (int)(~(unsigned)key);
+                if (a + B <= W - 1) {
+                    const unsigned lastval = lastM[(a + B - 1 - lo) % RS];
+                    if (entry < 0 || lastval <= vmin) entry = W - 1;
+                }
+                entry = UNI(entry);
+                y = entry;
+                if (lane == 0) m->entry = entry;
+                if (entry < 0) { err = 4; break; }
+            } else {
+                y = UNI(way[x + 1]) - 1;                    // guess: just left of where the row above sits now
+                yguess = y;
+            }
+        } else {
+            if (top) break;                                 // already final
+            int f = 0;
+            for (int spin = 0; spin < TR_SPIN_LIMIT; ++spin) {
+                f = UNI(__hip_atomic_load(&s_flag[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (f) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (f != 1) { err = 5; break; }                 // the chunk above failed (or timed out)
+            y = UNI(__hip_atomic_load(&s_yexit[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (y == yguess && xrec_lo <= x_lo) break;      // the guess was right and the whole chunk is recorded
+            check_merge = true;
+        }
+        int gcur = -1, yb = 0;
+        uint32_t win[4] = {0, 0, 0, 0};
+        int gpre = -1, ybpre = 0;
+        uint32_t pre[4] = {0, 0, 0, 0};
+        int blk = x >> 6;
+        int wcur = way[min(blk * 64 + lane, L - 1)];
+        int wnxt = way[max(blk * 64 - 64 + lane, 0)];
+        int ncreg = 0, yireg = 0;
+        if (phase == 1) { ncreg = newcol[min(blk * 64 + lane, L - 1)]; yireg = yin[min(blk * 64 + lane, L - 1)]; }
+        bool merged = false;
+        while (x >= x_lo && !err) {
+            x = UNI(x); y = UNI(y); blk = UNI(blk); gcur = UNI(gcur); yb = UNI(yb); gpre = UNI(gpre); ybpre = UNI(ybpre); cnt = UNI(cnt);
+            if (phase == 0) {
+                // ---- fast path (phase 0 only): rows of the current 16-row group / 64-row block whose answer
+                //      lies in the 64-cell sub-window holding the current column
+                while ((x >> 4) == gcur && (x >> 6) == blk && x >= x_lo) {
+                    const int af = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+                    const int ycf = min(y, af + min(B, W - af) - 1);
+                    if (y < af || ycf < yb || ycf > yb + 255) break;
+                    const int q0 = (ycf - yb) >> 6, shf = 15 - (x & 15);
+                    const uint32_t wq = q0 == 0 ? win[0] : q0 == 1 ? win[1] : q0 == 2 ? win[2] : win[3];
+                    const int cy = yb + 64 * q0 + lane;
+                    const unsigned long long mk = __ballot(cy <= ycf && cy >= af && !((wq >> shf) & 1u));
+                    if (!mk) break;
+                    const int t = 63 - __builtin_clzll(mk);
+                    const int yy = yb + 64 * q0 + t;
+                    const int cb = (int)((__ballot((wq >> (16 + shf)) & 1u) >> t) & 1ull);
+                    ncreg = (lane == (x & 63)) ? ((yy << 1) | (cb ^ 1)) : ncreg;
+                    yireg = (lane == (x & 63)) ? y : yireg;
+                    y = yy - cb;                            // diag: column to the left, up: stay
+                    cnt += cb ^ 1;
+                    --x;
+                    if (y < 0) break;
+                }
+                if (x < x_lo) break;
+                if (y < 0) { err = 3; break; }
+            }
+            if ((x >> 6) != blk) {
+                if (blk * 64 + lane < L) { newcol[blk * 64 + lane] = ncreg; yin[blk * 64 + lane] = yireg; }
+                blk = x >> 6;
+                wcur = wnxt;
+                wnxt = way[max(blk * 64 - 64 + lane, 0)];
+                if (phase == 1) { ncreg = newcol[min(blk * 64 + lane, L - 1)]; yireg = yin[min(blk * 64 + lane, L - 1)]; }
+            }
+            if (check_merge && x >= xrec_lo && __builtin_amdgcn_readlane(yireg, x & 63) == y) { merged = true; break; }
+            const int a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+            const int Bx = min(B, W - a);
+            if (y < a) { err = 1; break; }
+            int yc = min(y, a + Bx - 1);                     // past the band: implicit left moves
+            const int g = x >> 4, sh = 15 - (x & 15);
+            int found = -1, cbit = 0;
+            for (;;) {
+                if (g != gcur || yc < yb || yc > yb + 255) {
+                    const int want = max(lo, yc - 191);
+                    if (gpre == g && ybpre == want) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) win[q] = pre[q];
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) win[q] = dirs[(size_t)g * RS + (want + 64 * q + lane - lo) % RS];
+                    }
+                    gcur = g; yb = want;
+                    if (g > 0) {
+                        gpre = g - 1; ybpre = want;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) pre[q] = dirs[(size_t)(g - 1) * RS + (want + 64 * q + lane - lo) % RS];
+                    }
+                }
+                {
+                    const int q0 = (yc - yb) >> 6;
+                    const uint32_t wq = q0 == 0 ? win[0] : q0 == 1 ? win[1] : q0 == 2 ? win[2] : win[3];
+                    const int cy = yb + 64 * q0 + lane;
+                    const unsigned long long mk = __ballot(cy <= yc && cy >= a && !((wq >> sh) & 1u));
+                    if (mk) {
+                        const int t = 63 - __builtin_clzll(mk);
+                        found = yb + 64 * q0 + t;
+                        const unsigned long long ck = __ballot((wq >> (16 + sh)) & 1u);
+                        cbit = (int)((ck >> t) & 1ull);
+                    } else {
+#pragma unroll
+                        for (int q = 2; q >= 0; --q) {
+                            if (found < 0 && q < q0) {
+                                const int cy2 = yb + 64 * q + lane;
+                                const unsigned long long mk2 = __ballot(cy2 >= a && !((win[q] >> sh) & 1u));
+                                if (mk2) {
+                                    const int t = 63 - __builtin_clzll(mk2);
+                                    found = yb + 64 * q + t;
+                                    const unsigned long long ck = __ballot((win[q] >> (16 + sh)) & 1u);
+                                    cbit = (int)((ck >> t) & 1ull);
+                                }
+                            }
+                        }
+                    }
+                }
+                if (found >= 0) break;
+                if (yb <= a) { err = 2; break; }
+                yc = yb - 1;
+            }
+            if (err) break;
+            const int yy = found;
+            const int nv = cbit ? (yy << 1) : ((yy << 1) | 1);                       // PW:1394 (c) / PW:1404 (d)
+            if (phase == 1 && x >= xrec_lo) cnt -= __builtin_amdgcn_readlane(ncreg, x & 63) & 1;   // replaces a recorded step
+            cnt += nv & 1;
+            ncreg = (lane == (x & 63)) ? nv : ncreg;
+            yireg = (lane == (x & 63)) ? y : yireg;
+            y = cbit ? yy - 1 : yy;
+            --x;
+            if (x >= 0 && y < 0) { err = 3; break; }
+        }
+        if (blk * 64 + lane < L && (x < x_top)) { newcol[blk * 64 + lane] = ncreg; yin[blk * 64 + lane] = yireg; }
+        if (phase == 0) {
+            if (top) {
+                if (err) break;
+            } else {
+                // a failed guess is harmless: rows x+1 .. x_top are recorded (and counted), row x is where it broke off
+                xrec_lo = err ? x + 1 : x_lo;
+                if (err == 0) yout_guess = y;
+                err = 0;
+            }
+            if (top) { yout_guess = y; }
+        } else {
+            if (err) break;
+            if (merged && xrec_lo > x_lo) { err = 6; break; }   // merged into a guess that broke off: the true trace breaks there too
+            if (merged) y = yout_guess;                     // the rest of the chunk is what the guess recorded
+            yout_guess = y;
+        }
+    }
+    // a guess that broke off early leaves rows below xrec_lo unrecorded: phase 1 retraced through them (no merge
+    // is possible there), so every row of the chunk is final now
+    if (lane == 0) {
+        s_yexit[wv] = yout_guess;
+        s_cnt[wv] = cnt;
+        __hip_atomic_store(&s_flag[wv], err ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (err) {
+        if (lane == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+        return;
+    }
+    if (wv == 0 && lane == 0) {
+        int tot = 0;
+        for (int c = 0; c < nch; ++c) tot += s_cnt[c];     // all chunks above are final (hand-over order)
+        m->nnew = tot;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // commit: apply one job's new placement to the resident state (one work-group):
 //   Column_Updater (PW:1222-1243) for every existing column the row touches, Column_Adder
 //   (PW:1245-1332) for every new column, then W_Con (PW:706-763): drop columns without a base and
@@ -1704,6 +1939,7 @@ struct pwr_ctx {
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
     int threads = 256;
+    int par_trace = 1;                    // 1: speculative-parallel traceback (k_trace_par), 0: single-wave k_trace_wp
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int fill_mode = 3;
     int wp_waves = 5;                     // waves per DP of the v2 wave pipeline: 9/8/5/4/3 with 2/3/4/6/8 columns per lane                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 3: wave pipeline in lock-step rounds (k_fill_v2)
@@ -2167,7 +2403,8 @@ static int run_batch(pwr_ctx *c, int k0, int n, int *done)
     if (rc) return rc;
     hipLaunchKernelGGL(k_gather, dim3(n), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids + k0);
     if ((rc = launch_fill(c, n))) return rc;
-    if (c->fill_mode) hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
+    if (c->fill_mode && c->par_trace) hipLaunchKernelGGL(k_trace_par, dim3(n), dim3(TRK * 64), 0, c->stream, c->st, c->jb);
+    else if (c->fill_mode) hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
     else hipLaunchKernelGGL(k_trace, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
     hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n);
     HIPC(hipGetLastError());
@@ -2311,6 +2548,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "window")) { if (value < 1 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
     if (!strcmp(key, "fill")) { if (c->on_device || (value != 0 && value != 1 && value != 3)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
+    if (!strcmp(key, "ptrace")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
     if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
     if (!strcmp(key, "threads")) {
