@@ -117,10 +117,6 @@ def main():
     g.trim_ends()
     score0 = g.total_score()            # first device call: uploads the MSA into HBM
     note(f"resident in HBM, score {score0}")
-    for i in range(args.warmup):
-        run_round(f"warm-up round {i + 1}")
-        note(f"warm-up round {i + 1} done")
-    g.reset_stats()
 
     def run_round(tag):
         """One realignment round with a heartbeat on stderr (a full-size round runs for minutes)."""
@@ -138,6 +134,11 @@ def main():
         finally:
             done.set()
             th.join()
+
+    for i in range(args.warmup):
+        run_round(f"warm-up round {i + 1}")
+        note(f"warm-up round {i + 1} done")
+    g.reset_stats()
 
     def fence():
         if world > 1:

@@ -894,6 +894,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_wp(DState st, JobBufs jb)
 #define V2_PD 64
 #define V2_R 8
 #define V2_SPINS 48
+#define FBIG 0x3fffffff                              // neutral element of the fast path's min-scan (G + FBIG stays below 2^31)
 #define UNI(v) __builtin_amdgcn_readfirstlane(v)
 
 #define V2_CASE(SGARR)                                                                           \
@@ -1082,10 +1083,10 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 #endif
                     const int rel0 = rel00 - af;
                     int tg[C];
-                    int run = PWR_BIG;
+                    int run = FBIG;
 #pragma unroll
                     for (int i = 0; i < C; ++i) {
-                        tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bxf) ? t3[i] : PWR_BIG;
+                        tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bxf) ? t3[i] : FBIG;
                         run = min(run, tg[i]);
                     }
                     const int incl = wave_incl_min(run);
@@ -1094,12 +1095,14 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 #ifdef PWR_STAMPS
                     const unsigned long long f3 = __builtin_amdgcn_s_memtime();
 #endif
-                    int p = min(P_inf, excl);
+                    // cells left of the band come before its first cell in scan order, so their p is still the
+                    // neutral element FBIG = 2^30 - 1 and G + p lands at or above INF by itself; the min keeps it there
+                    int p = min(min(P_inf, excl), FBIG);
 #pragma unroll
                     for (int i = 0; i < C; ++i) {
                         accA[i] |= (tg[i] >= p) ? bit : 0u;
                         p = min(p, tg[i]);
-                        Mprev[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
+                        Mprev[i] = min((unsigned)(gg[i] + p), PWR_INF);
                     }
                     ++x;
                     if (lane == 63) {
