@@ -278,10 +278,11 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     if (jb.wpNW > 0) {
         // Row descriptors for k_fill_v2: what every wave would otherwise recompute per DP row.  Wave w owns the
         // macro-strip ms = ms_lo + ((w - ms_lo) mod NW) in row x; 4 flag bits per wave:
-        //   bit0 "ordinary row": the wave has work in rows x-1 and x on the same macro-strip, 0 < x < L-1
+        //   bit0 "ordinary row": the wave has work in rows x-1 and x on the same macro-strip, 0 < x < L-1, and the
+        //        score left of the macro-strip is not the virtual extension G + Ptot(x-1) of PW:285-295
         //   bit1 needs the left neighbour's running minimum (its macro-strip is not the band's first)
-        //   bits2-3 where the score left of the macro-strip comes from: 0 = INF (PW:276), 1 = the neighbour's
-        //           boundary score of row x-1, 2 = virtual extension G + Ptot(x-1) (PW:285-295)
+        //   bit2 the score left of the macro-strip is the neighbour's boundary score of row x-1 (else INF, PW:276)
+        //   bit3 the band ends in this macro-strip (the wave posts the row's total minimum)
         uint4 *desc = jb.desc + (size_t)job * jb.Lmax;
         const int NWg = jb.wpNW, MSg = jb.wpMS;
         for (int x = tid; x < L; x += GATHER_NT) {
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
                 const bool ranp = x > 0 && msp == msw && msp <= phi;
                 const int yq = lo + msw * MSg - 1;
                 const unsigned kind = (x == 0 || yq < ap) ? 0u : (yq < ap + bp ? 1u : 2u);
-                const unsigned bits = ((ranp && x < L - 1) ? 1u : 0u) | (msw > mlo ? 2u : 0u) | (kind << 2);
+                const unsigned bits = ((ranp && x < L - 1 && kind != 2u) ? 1u : 0u) | (msw > mlo ? 2u : 0u) | (kind == 1u ? 4u : 0u) | (msw == mhi ? 8u : 0u);
                 fl |= (unsigned long long)bits << (4 * w);
             }
             desc[x] = make_uint4((unsigned)ax, (unsigned)bx | ((unsigned)st.seq[off + x] << 16), (unsigned)fl, (unsigned)(fl >> 32));
@@ -890,45 +891,74 @@ __global__ __launch_bounds__(NW * 64) void k_fill_wp(DState st, JobBufs jb)
 //   * a wave may retire up to V2_R rows per round (its left neighbour is that far ahead), so the
 //     barrier is amortised; all control state is kept wave-uniform (SGPRs, scalar branches).
 // ---------------------------------------------------------------------------------------------
-#define V2_D 32
-#define V2_PD 64
-#define V2_R 8
-#define V2_SPINS 48
+#define V2_D 64                                      // mailbox depth (rows); a wave is never more than V2_R rows ahead of its reader
+#define V2_PD 512
+#define V2_R 32
+#define V2_SPINS 256
 #define FBIG 0x3fffffff                              // neutral element of the fast path's min-scan (G + FBIG stays below 2^31)
 #define UNI(v) __builtin_amdgcn_readfirstlane(v)
 
-#define V2_CASE(SGARR)                                                                           \
-    _Pragma("unroll") for (int i = 0; i < C; ++i) {                                              \
-        const int pm1 = i ? (int)Mprev[i > 0 ? i - 1 : 0] : pm1_0;                               \
-        const int d = pm1 + SGARR[i];                                                            \
-        const int u = (int)Mprev[i] + ug[i];                                                     \
-        accC[i] |= (d <= u) ? bit : 0u;                                                          \
-        t3[i] = min(min(d, u), ig[i]);                                                           \
-    }
+// shift a traceback-bit accumulator left by one and insert the lane's bit of MASK (a v_cmp result): one VALU op
+__device__ __forceinline__ unsigned acc_push(unsigned acc, unsigned long long mask)
+{
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(acc), "=s"(carry_out) : "s"(mask));
+    return acc;
+}
+#define ICMP_SGE 39
+#define ICMP_SLE 41
 
-#define V2_LOAD(MSX, A0, A1, A2, A3, AU, AG, AI, GL)                                             \
+// records of macro-strip MSX: the four substitution columns S_b - G go to this wave's LDS table SLOT (read back
+// per DP row with the row's base as the index), the rest stays in registers
+#define V2_LOAD(MSX, SLOT, AU, AG, AI, GL)                                                       \
     {                                                                                            \
         _Pragma("unroll") for (int i = 0; i < C; ++i) {                                          \
             const int y_ = lo + (MSX) * MS + lc + i;                                             \
             int4 p_ = make_int4(PWR_BIG / 2, PWR_BIG / 2, PWR_BIG / 2, PWR_BIG / 2);             \
             int4 q_ = make_int4(PWR_BIG / 2, 0, PWR_BIG / 2, 0);                                 \
             if (y_ <= hi) { p_ = rec2[2 * (y_ - lo)]; q_ = rec2[2 * (y_ - lo) + 1]; }            \
-            A0[i] = p_.x; A1[i] = p_.y; A2[i] = p_.z; A3[i] = p_.w;                              \
+            ldsS[wave][SLOT][0][lc + i] = p_.x; ldsS[wave][SLOT][1][lc + i] = p_.y;              \
+            ldsS[wave][SLOT][2][lc + i] = p_.z; ldsS[wave][SLOT][3][lc + i] = p_.w;              \
             AU[i] = q_.x; AG[i] = q_.y; AI[i] = q_.z;                                            \
         }                                                                                        \
         const int yq_ = lo + (MSX) * MS - 1;                                                     \
         GL = (yq_ >= lo && yq_ <= hi) ? UNI(rec2[2 * (yq_ - lo) + 1].y) : 0;                     \
     }
 
+#ifdef PWR_STAMPS
+#define ST_NOW() __builtin_amdgcn_s_memtime()
+#define ST_DECL unsigned long long st_fast = 0, st_spin = 0, st_gen = 0, st_bar = 0, st_load = 0, st_t = 0, st_rows = 0, st_entries = 0, st_spins = 0, st_grows = 0;
+#define ST_BEGIN() st_t = ST_NOW();
+#define ST_END(ACC) ACC += ST_NOW() - st_t;
+#else
+#define ST_DECL
+#define ST_BEGIN()
+#define ST_END(ACC)
+#endif
 template <int NW, int C>
 __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 {
+    ST_DECL
     constexpr int MS = 64 * C, RS = NW * MS;
-    __shared__ uint2 mbD[NW][V2_D];                 // {P_end, M_last} of row x in slot x % V2_D: one aligned 8-byte store
-    __shared__ int wseq[NW];                         // rows wave w is done with; stored after the row's mbD entry, and LDS
-                                                    // executes one wave's stores in order, so seq > x means entry x is there
-    __shared__ uint2 ptb[V2_PD];                    // {Ptot, tag}
+    // What lane 63 of a wave publishes per DP row.  Every item is one 64-bit word {value, row + 1}, stored and loaded
+    // with single 8-byte LDS accesses (relaxed atomics, so the compiler can neither split nor merge them): the row
+    // number makes it self-validating, a reader needs no other signal.  Behind the real slots of each array there
+    // is one private dump slot per lane, so that a store is steered by its index alone (lane 63 to the real slot,
+    // the others to their dump slot) instead of by EXEC:
+    //   mbQ[2 * (w * V2_D + x % V2_D) + 0]  P_end of row x of wave w (the running minimum its right neighbour continues)
+    //   mbQ[2 * (w * V2_D + x % V2_D) + 1]  M_last, the score of its last column
+    //   ptQ[x % V2_PD]                      Ptot, the minimum of the whole row x
+    constexpr int MBDUMP = NW * V2_D, PTDUMP = V2_PD;
+    __shared__ unsigned long long mbQ[2 * (MBDUMP + NW * 64)];
+    __shared__ unsigned long long ptQ[PTDUMP + NW * 64];
+    __shared__ __attribute__((aligned(16))) int ldsS[NW][2][4][MS];
+    __shared__ int rdone[NW];                       // round + 1 once wave w has left that round
     __shared__ int s_done;
+#define LD64(REF) __hip_atomic_load(&(REF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define ST64(REF, VAL, TAG) __hip_atomic_store(&(REF), ((unsigned long long)(unsigned)(TAG) << 32) | (unsigned)(VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define MBP(W_, X_) mbQ[2 * ((W_) * V2_D + ((X_) & (V2_D - 1)))]
+#define MBM(W_, X_) mbQ[2 * ((W_) * V2_D + ((X_) & (V2_D - 1))) + 1]
+#define PTB(X_) ptQ[(X_) & (V2_PD - 1)]
 
     const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wave = UNI(tid >> 6);
@@ -936,9 +966,9 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     const int L = UNI(m->L);
     if (L <= 0 || !m->ok) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
-    for (int i = tid; i < NW * V2_D; i += NW * 64) (&mbD[0][0])[i] = make_uint2(0, 0);
-    if (tid < NW) wseq[tid] = 0;
-    for (int i = tid; i < V2_PD; i += NW * 64) ptb[i] = make_uint2(0, 0);
+    for (int i = tid; i < 2 * (MBDUMP + NW * 64); i += NW * 64) mbQ[i] = 0;
+    for (int i = tid; i < PTDUMP + NW * 64; i += NW * 64) ptQ[i] = 0;
+    if (tid < NW) rdone[tid] = 0;
     if (tid == 0) s_done = 0;
     __syncthreads();
 
@@ -950,19 +980,21 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
     const int wl = (wave + NW - 1) % NW;
     const int lc = lane * C;
+    const int mb_dump = MBDUMP + wave * 64 + lane, pt_dump = PTDUMP + wave * 64 + lane;   // where lanes 0..62 "publish" to
 
-    // per-column constants of the current (sg*, ug, gg, ig) and the prefetched (n*) macro-strip
-    int sg0[C], sg1[C], sg2[C], sg3[C], ug[C], gg[C], ig[C];
-    int n0[C], n1[C], n2[C], n3[C], nu[C], ng[C], ni[C];
+    // per-column constants of the current (ug, gg, ig) and the prefetched (nu, ng, ni) macro-strip
+    int ug[C], gg[C], ig[C];
+    int nu[C], ng[C], ni[C];
     int gleft = 0, gleftn = 0;
     int ms = wave, msn = wave + NW;
-    V2_LOAD(ms, sg0, sg1, sg2, sg3, ug, gg, ig, gleft)
-    V2_LOAD(msn, n0, n1, n2, n3, nu, ng, ni, gleftn)
+    int cs = 0;                                                     // LDS table slot of the current macro-strip
+    V2_LOAD(ms, 0, ug, gg, ig, gleft)
+    V2_LOAD(msn, 1, nu, ng, ni, gleftn)
 
     unsigned Mprev[C], accA[C], accC[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) { Mprev[i] = 0; accA[i] = accC[i] = 0; }
-    int gacc = -1;                                          // 16-row group the accumulators belong to
+    int gacc = -1, nacc = 0;                                // 16-row group the accumulators belong to, rows pushed so far
     int ran_prev = 0, finished = 0;
     int x = 0, blk = 0;
     int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
@@ -979,17 +1011,25 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     const int max_rounds = 4 * L + 64 * NW + 1024;
     int round = 0;
 
+    // the accumulators take one bit per DP row, most significant first; rows of the group this wave had no
+    // work in are zeros
+#define V2_ALIGN_ACC(WANT)                                                                       \
+    if (nacc != (WANT)) {                                                                        \
+        const int sh_ = (WANT) - nacc;                                                           \
+        _Pragma("unroll") for (int i = 0; i < C; ++i) { accA[i] <<= sh_; accC[i] <<= sh_; }      \
+        nacc = (WANT);                                                                           \
+    }
 #define V2_FLUSH()                                                                               \
     if (gacc >= 0) {                                                                             \
+        V2_ALIGN_ACC(16)                                                                         \
         uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;                \
         _Pragma("unroll") for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; } \
-        gacc = -1;                                                                               \
+        gacc = -1; nacc = 0;                                                                     \
     }
 #define V2_NEXT_ROW()                                                                            \
     {                                                                                            \
         a_prev = a; Bx_prev = Bx;                                                                \
         ++x;                                                                                     \
-        if (lane == 63) __hip_atomic_store(&wseq[wave], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
         if (x < L) {                                                                             \
             if ((x >> 6) != blk) {                                                               \
                 blk = x >> 6;                                                                    \
@@ -1008,113 +1048,137 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
         }                                                                                        \
     }
 
-#ifdef PWR_STAMPS
-    unsigned long long fs0 = 0, fs1 = 0, fs2 = 0, fs3 = 0, fsn = 0;
-#endif
     for (; round < max_rounds; ++round) {
         int budget = V2_R;
         while (budget > 0) {
             // loop-carried control state is wave-uniform; say so, so it lives in SGPRs and branches are scalar
             finished = UNI(finished);
             if (finished) break;
-            ran_prev = UNI(ran_prev); gacc = UNI(gacc); blk = UNI(blk); ms = UNI(ms); gleft = UNI(gleft);
-            // ---- fast path: a run of ordinary rows (same macro-strip in the band, not the first / last row, same
-            //      16-row group and 64-row block, previous row done by this wave) as straight-line code.
-            //      The left neighbour's mailbox entry of the NEXT row is fetched while the current row is computed.
+            ran_prev = UNI(ran_prev); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); ms = UNI(ms); cs = UNI(cs); gleft = UNI(gleft);
+            // ---- fast path: a run of ordinary rows (flagged by the gather: same macro-strip in the band as in the
+            //      row before, not the first / last row) of the current 16-row group and 64-row block, as one
+            //      straight-line loop body.  Everything the left neighbour posted stays in VGPRs (an LDS read gives
+            //      every lane the same value), lane 63 publishes by index, and the row's substitution column comes
+            //      from the LDS table -- no EXEC changes, no scalar round trips, one exit test.
             bool not_ready = false;
-            if ((x >> 4) == gacc) {
-                int avail = UNI(__hip_atomic_load(&wseq[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                uint2 fD2 = mbD[wl][x & (V2_D - 1)];                    // {P_end(x), M_last(x)} of the left neighbour
-                unsigned mlast = UNI(mbD[wl][(x - 1) & (V2_D - 1)].y);  // M_last(x-1)
+            if ((x >> 4) == gacc && ran_prev) {
+                unsigned mlast_v = (unsigned)LD64(MBM(wl, x - 1));                   // M_last(x-1) of the left neighbour
                 const int y0f = lo + ms * MS;
                 const int rel00 = y0f + lc;
-                // rows this loop may take: same 16-row group, row x+1 in the same 64-row block, not the last row
-                const int xstop = min(min(L - 1, ((x >> 4) + 1) << 4), ((blk + 1) << 6) - 1);
+                // rows this loop may take: up to the last but one of the 64-row block (the general path reloads the
+                // per-block registers), not the last row
+                const int xstop = UNI(min(L - 1, ((blk + 1) << 6) - 1));
                 const int x_in = x;
-                while (budget > 0 && x < xstop) {
+                V2_ALIGN_ACC(x & 15)
+                // the substitution column of the NEXT row is fetched from the LDS table while the current row is computed
+                unsigned db = (unsigned)__builtin_amdgcn_readlane((int)dcb, x & 63);
+                int sgr[C];
+#pragma unroll
+                for (int i = 0; i < C; ++i) sgr[i] = ldsS[wave][cs][min(db >> 16, 3u)][lc + i];
+                // have the loads above land before the loop, so that the waits inside it are the steady-state ones
+#pragma unroll
+                for (int i = 0; i < C; ++i) asm volatile("" : "+v"(sgr[i]));
+                asm volatile("" : "+v"(mlast_v));
+                int cnt = min(budget, xstop - x) - 1;                                // rows the loop may still take, less one
+                int bail = 0;
 #ifdef PWR_STAMPS
-                    const unsigned long long f0 = __builtin_amdgcn_s_memtime();
+                ++st_entries; const unsigned long long st_f0 = ST_NOW(); unsigned long long st_sp = 0;
 #endif
-                    x = UNI(x); budget = UNI(budget); avail = UNI(avail); mlast = UNI(mlast);
-                    const unsigned fl = (unsigned)__builtin_amdgcn_readlane((int)dcf, x & 63) & 15u;
-                    if (!(fl & 1u)) break;                                           // not an ordinary row: general path
+                while (true) {
+                    x = UNI(x); cnt = UNI(cnt); gacc = UNI(gacc); db = UNI(db); bail = UNI(bail);
+                    const int fl = __builtin_amdgcn_readlane((int)dcf, x & 63);
+                    // one exit test (sign bits): no rows left (or the row before gave up) / not an ordinary row (bit 0 clear)
+                    if ((cnt | ~(fl << 31)) < 0) break;
                     const int af = __builtin_amdgcn_readlane((int)dca, x & 63);
-                    const unsigned db = (unsigned)__builtin_amdgcn_readlane((int)dcb, x & 63);
-                    const int Bxf = (int)(db & 0xffffu), sxf = (int)(db >> 16);
-                    const bool needPf = (fl & 2u) != 0;
-                    const unsigned kind = fl >> 2;
-                    if (needPf && x >= avail) {
-                        // the neighbour has not posted row x yet: wait for it a little (it is usually a few hundred
-                        // cycles away) before giving the round up; bounded, the barrier below is the fallback
-                        for (int spin = 0; spin < V2_SPINS; ++spin) {
-                            avail = UNI(__hip_atomic_load(&wseq[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                            if (x < avail) break;
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        if (x >= avail) { not_ready = true; break; }
-                        fD2 = mbD[wl][x & (V2_D - 1)];
-                    }
-                    unsigned fTx = 0;
-                    if (kind == 2u) {
-                        const uint2 fT2 = ptb[(x - 1) & (V2_PD - 1)];
-                        fTx = UNI(fT2.x);
-                        if (UNI(fT2.y) != (unsigned)x) { not_ready = true; break; }
-                    }
-                    const unsigned fPx = UNI(fD2.x), fMx = UNI(fD2.y);
-#ifdef PWR_STAMPS
-                    const unsigned long long f1 = __builtin_amdgcn_s_memtime();
-#endif
-                    --budget;
-                    fD2 = mbD[wl][(x + 1) & (V2_D - 1)];                             // next row's entry, used only if seq allows
-                    const int Mleftf = kind == 1u ? (int)mlast : (kind == 2u ? gleft + (int)fTx : (int)PWR_INF);
-                    const int P_inf = needPf ? (int)fPx : PWR_BIG;
-                    mlast = fMx;                                                     // valid whenever the next row needs it
-                    const unsigned bit = 1u << (15 - (x & 15));
-                    const int pm1_0 = __builtin_amdgcn_update_dpp(Mleftf, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
-                    int t3[C];
-                    switch (sxf) {
-                    case 0: V2_CASE(sg0) break;
-                    case 1: V2_CASE(sg1) break;
-                    case 2: V2_CASE(sg2) break;
-                    default: V2_CASE(sg3) break;
-                    }
-#ifdef PWR_STAMPS
-                    const unsigned long long f2 = __builtin_amdgcn_s_memtime();
-#endif
+                    const int Bxf = (int)(db & 0xffffu);
+                    db = (unsigned)__builtin_amdgcn_readlane((int)dcb, (x + 1) & 63);
+                    const int Mleft_v = (fl & 4) ? (int)mlast_v : (int)PWR_INF;
+                    const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft_v, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
                     const int rel0 = rel00 - af;
                     int tg[C];
                     int run = FBIG;
 #pragma unroll
                     for (int i = 0; i < C; ++i) {
-                        tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bxf) ? t3[i] : FBIG;
+                        const int pm1 = i ? (int)Mprev[i > 0 ? i - 1 : 0] : pm1_0;
+                        const int d = pm1 + sgr[i];
+                        const int u = (int)Mprev[i] + ug[i];
+                        accC[i] = acc_push(accC[i], __builtin_amdgcn_sicmp(d, u, ICMP_SLE));
+                        const int t3 = min(min(d, u), ig[i]);
+                        tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bxf) ? t3 : FBIG;
                         run = min(run, tg[i]);
                     }
+#pragma unroll
+                    for (int i = 0; i < C; ++i) sgr[i] = ldsS[wave][cs][min(db >> 16, 3u)][lc + i];
+                    // the left neighbour's entry of this row is only needed after the scan: ask for it now, and if it
+                    // is not there yet wait for it HERE -- the neighbour is then half a row ahead, not a whole one
+                    unsigned long long fP = LD64(MBP(wl, x)), fM = LD64(MBM(wl, x));
+                    __builtin_amdgcn_sched_barrier(0);
                     const int incl = wave_incl_min(run);
                     const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
-                    const int P_end = min(P_inf, __builtin_amdgcn_readlane(incl, 63));
+                    if (fl & 2) {
+                        const unsigned tagx = (unsigned)(x + 1);
+#define V2_BOTH_THERE() (UNI(((unsigned)(fP >> 32) ^ tagx) | ((unsigned)(fM >> 32) ^ tagx)) == 0u)
+                        if (!V2_BOTH_THERE()) {
+                            // bounded; gives up at once when the neighbour has left the round (rdone is stored after its
+                            // last entry, and LDS keeps one wave's stores in order)
 #ifdef PWR_STAMPS
-                    const unsigned long long f3 = __builtin_amdgcn_s_memtime();
+                            const unsigned long long st_s0 = ST_NOW(); ++st_spins;
 #endif
-                    // cells left of the band come before its first cell in scan order, so their p is still the
-                    // neutral element FBIG = 2^30 - 1 and G + p lands at or above INF by itself; the min keeps it there
-                    int p = min(min(P_inf, excl), FBIG);
+                            for (int spin = 0; spin < V2_SPINS; ++spin) {
+                                const int rd = UNI(__hip_atomic_load(&rdone[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                                __builtin_amdgcn_s_sleep(1);
+                                fP = LD64(MBP(wl, x)); fM = LD64(MBM(wl, x));
+                                if (V2_BOTH_THERE() || rd == round + 1) break;
+                            }
+#ifdef PWR_STAMPS
+                            st_sp += ST_NOW() - st_s0;
+#endif
+                            if (!V2_BOTH_THERE()) bail = 1;
+                        }
+#undef V2_BOTH_THERE
+                    }
+                    if (!bail) {
+                        const int P_in_v = (fl & 2) ? (int)(unsigned)fP : PWR_BIG;
+                        const int P_end_v = min(P_in_v, incl);                       // lane 63: the row's running minimum so far
+                        // cells left of the band come before its first cell in scan order, so their p is still the
+                        // neutral element FBIG = 2^30 - 1 and G + p lands at or above INF by itself; the min keeps it there
+                        int p = min(min(P_in_v, excl), FBIG);
 #pragma unroll
-                    for (int i = 0; i < C; ++i) {
-                        accA[i] |= (tg[i] >= p) ? bit : 0u;
-                        p = min(p, tg[i]);
-                        Mprev[i] = min((unsigned)(gg[i] + p), PWR_INF);
+                        for (int i = 0; i < C; ++i) {
+                            accA[i] = acc_push(accA[i], __builtin_amdgcn_sicmp(tg[i], p, ICMP_SGE));
+                            p = min(p, tg[i]);
+                            Mprev[i] = min((unsigned)(gg[i] + p), PWR_INF);
+                        }
+                        mlast_v = (unsigned)fM;                                      // valid whenever the next row needs it
+                        ++x; --cnt;
+                        {
+                            const int qi = lane == 63 ? wave * V2_D + ((x - 1) & (V2_D - 1)) : mb_dump;
+                            ST64(mbQ[2 * qi], P_end_v, x);
+                            ST64(mbQ[2 * qi + 1], Mprev[C - 1], x);
+                        }
+                        if (fl & 8)                                                  // the band ends in this macro-strip
+                            ST64(ptQ[lane == 63 ? ((x - 1) & (V2_PD - 1)) : pt_dump], P_end_v, x);
+                        if ((x & 15) == 0) {                                         // the 16-row group is complete
+                            uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;
+#pragma unroll
+                            for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; }
+                            gacc = x >> 4;
+                        }
+                    } else {
+                        cnt = -1;                                // the neighbour will not post row x in this round
                     }
-                    ++x;
-                    if (lane == 63) {
-                        mbD[wave][(x - 1) & (V2_D - 1)] = make_uint2((unsigned)P_end, Mprev[C - 1]);
-                        if (af + Bxf <= y0f + MS) ptb[(x - 1) & (V2_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)x);
-                        __hip_atomic_store(&wseq[wave], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+                }
 #ifdef PWR_STAMPS
-                    { const unsigned long long f4 = __builtin_amdgcn_s_memtime(); fs0 += f1 - f0; fs1 += f2 - f1; fs2 += f3 - f2; fs3 += f4 - f3; ++fsn; }
+                st_fast += ST_NOW() - st_f0 - st_sp; st_spin += st_sp; st_rows += x - x_in;
 #endif
+                budget -= x - x_in;
+                if (bail) {                                      // take the unfinished row back and leave the round
+#pragma unroll
+                    for (int i = 0; i < C; ++i) accC[i] >>= 1;
+                    not_ready = true;
                 }
                 if (x != x_in) {                                                     // resynchronise the general path's row state
+                    nacc = x & 15;
                     const int apw = __builtin_amdgcn_readlane(wcur, (x - 1) & 63);
                     a_prev = max(0, apw - H); Bx_prev = min(B, W - a_prev);
                     a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
@@ -1122,9 +1186,12 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 }
             }
             if (not_ready || budget <= 0) break;
-
+            ST_BEGIN()
+#ifdef PWR_STAMPS
+            ++st_grows;
+#endif
             x = UNI(x); ms = UNI(ms); msn = UNI(msn); a = UNI(a); a_prev = UNI(a_prev); Bx_prev = UNI(Bx_prev);
-            sx = UNI(sx); gacc = UNI(gacc); blk = UNI(blk); gleft = UNI(gleft); gleftn = UNI(gleftn); ran_prev = UNI(ran_prev);
+            sx = UNI(sx); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); gleft = UNI(gleft); gleftn = UNI(gleftn); ran_prev = UNI(ran_prev); cs = UNI(cs);
             const int Bx = min(B, W - a);
             const int ms_lo = (a - lo) / MS, ms_hi = (a + Bx - 1 - lo) / MS;
             if (ms < ms_lo) {
@@ -1132,23 +1199,23 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 ms += NW;
                 if (ms == msn) {
 #pragma unroll
-                    for (int i = 0; i < C; ++i) {
-                        sg0[i] = n0[i]; sg1[i] = n1[i]; sg2[i] = n2[i]; sg3[i] = n3[i];
-                        ug[i] = nu[i]; gg[i] = ng[i]; ig[i] = ni[i];
-                    }
+                    for (int i = 0; i < C; ++i) { ug[i] = nu[i]; gg[i] = ng[i]; ig[i] = ni[i]; }
                     gleft = gleftn;
+                    cs ^= 1;
                 } else {
                     while (ms < ms_lo) ms += NW;
-                    V2_LOAD(ms, sg0, sg1, sg2, sg3, ug, gg, ig, gleft)
+                    V2_LOAD(ms, cs, ug, gg, ig, gleft)
                 }
                 msn = ms + NW;
-                V2_LOAD(msn, n0, n1, n2, n3, nu, ng, ni, gleftn)
+                V2_LOAD(msn, cs ^ 1, nu, ng, ni, gleftn)
                 ran_prev = 0;
+                ST_END(st_load)
                 continue;
             }
             if (ms > ms_hi) {                               // no work for this wave in row x
                 ran_prev = 0;
                 V2_NEXT_ROW()
+                ST_END(st_gen)
                 continue;
             }
             // ---- inputs of (x, ms): written by the left neighbour before the last barrier?
@@ -1157,15 +1224,23 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
             const bool needP = ms > ms_lo;
             const bool needM = x > 0 && yq >= a_prev && yq < a_prev + Bx_prev;
             const bool needT = x > 0 && ((yq >= a_prev + Bx_prev) || !ran_prev);
-            const int seqL = UNI(__hip_atomic_load(&wseq[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-            const uint2 eD2 = mbD[wl][x & (V2_D - 1)];                  // {P_end(x), M_last(x)} of the left neighbour
-            const uint2 eM2 = mbD[wl][(x - 1) & (V2_D - 1)];
-            const uint2 eT2 = ptb[(x - 1) & (V2_PD - 1)];
-            const unsigned ePx = UNI(eD2.x), ePy = UNI(eD2.y);
-            const unsigned eMy = UNI(eM2.y);
-            const unsigned eTx = UNI(eT2.x), eTy = UNI(eT2.y);
-            const bool ready = (!needP || x < seqL) && (!needM || x - 1 < seqL) && (!needT || eTy == (unsigned)x);
-            if (!ready) break;
+            // bounded wait: the neighbour is usually within a row of posting what is missing; give up at once when it
+            // has left the round (rdone is stored after its last entry, LDS keeps one wave's stores in order)
+            unsigned ePx = 0, ePy = 0, eMy = 0, eTx = 0;
+            bool ready = false;
+            for (int spin = 0; spin < V2_SPINS; ++spin) {
+                const int rd = UNI(__hip_atomic_load(&rdone[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (spin) __builtin_amdgcn_s_sleep(1);
+                const unsigned long long eP = LD64(MBP(wl, x)), eQ = LD64(MBM(wl, x));   // P_end(x), M_last(x) of the left neighbour
+                const unsigned long long eM = LD64(MBM(wl, x - 1)), eT = LD64(PTB(x - 1));
+                ePx = UNI((unsigned)eP); ePy = UNI((unsigned)eQ);
+                eMy = UNI((unsigned)eM);
+                eTx = UNI((unsigned)eT);
+                ready = (!needP || (UNI((unsigned)(eP >> 32)) == (unsigned)(x + 1) && UNI((unsigned)(eQ >> 32)) == (unsigned)(x + 1))) &&
+                        (!needM || UNI((unsigned)(eM >> 32)) == (unsigned)x) && (!needT || UNI((unsigned)(eT >> 32)) == (unsigned)x);
+                if (ready || rd == round + 1) break;
+            }
+            if (!ready) { ST_END(st_gen) break; }
             --budget;
             int Mleft = (int)PWR_INF;
             if (x == 0) Mleft = 0;
@@ -1178,21 +1253,20 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 for (int i = 0; i < C; ++i) Mprev[i] = (unsigned)(gg[i] + (int)eTx);
             }
             if ((x >> 4) != gacc) { V2_FLUSH() gacc = x >> 4; }
-            const unsigned bit = 1u << (15 - (x & 15));
+            V2_ALIGN_ACC(x & 15)
             const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
-            int t3[C];
-            switch (sx) {                                                            // PW:1503 Score(y, Seq_Bases[x])
-            case 0: V2_CASE(sg0) break;
-            case 1: V2_CASE(sg1) break;
-            case 2: V2_CASE(sg2) break;
-            default: V2_CASE(sg3) break;
-            }
+            const int sxc = min(max(sx, 0), 3);                                      // PW:1503 Score(y, Seq_Bases[x])
             const int rel0 = y0 + lc - a;
             int tg[C];
             int run = PWR_BIG;
 #pragma unroll
             for (int i = 0; i < C; ++i) {
-                tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bx) ? t3[i] : PWR_BIG;
+                const int pm1 = i ? (int)Mprev[i > 0 ? i - 1 : 0] : pm1_0;
+                const int d = pm1 + ldsS[wave][cs][sxc][lc + i];
+                const int u = (int)Mprev[i] + ug[i];
+                accC[i] = (accC[i] << 1) | ((d <= u) ? 1u : 0u);
+                const int t3 = min(min(d, u), ig[i]);
+                tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bx) ? t3 : PWR_BIG;
                 run = min(run, tg[i]);
             }
             const int incl = wave_incl_min(run);
@@ -1202,7 +1276,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
             if (x != L - 1) {
 #pragma unroll
                 for (int i = 0; i < C; ++i) {
-                    accA[i] |= (tg[i] >= p) ? bit : 0u;
+                    accA[i] = (accA[i] << 1) | ((tg[i] >= p) ? 1u : 0u);
                     p = min(p, tg[i]);
                     Mprev[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
                 }
@@ -1222,19 +1296,25 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 for (int i = 0; i < C; ++i) {
                     const unsigned lf = i ? Mn[i > 0 ? i - 1 : 0] : left0;
                     const bool inb = (unsigned)(rel0 + i) < (unsigned)Bx;
-                    if (((fa >> i) & 1u) || (inb && Mn[i] == lf)) accA[i] |= bit;
+                    accA[i] = (accA[i] << 1) | ((((fa >> i) & 1u) || (inb && Mn[i] == lf)) ? 1u : 0u);
                     lastM[wave * MS + lc + i] = inb ? Mn[i] : 0xffffffffu;
                     Mprev[i] = Mn[i];
                 }
             }
+            nacc = (x & 15) + 1;
             if (lane == 63) {
-                mbD[wave][x & (V2_D - 1)] = make_uint2((unsigned)P_end, Mprev[C - 1]);
-                if (ms == ms_hi) ptb[x & (V2_PD - 1)] = make_uint2((unsigned)P_end, (unsigned)(x + 1));
+                ST64(MBP(wave, x), P_end, x + 1);
+                ST64(MBM(wave, x), Mprev[C - 1], x + 1);
+                if (ms == ms_hi) ST64(PTB(x), P_end, x + 1);
             }
             ran_prev = 1;
             V2_NEXT_ROW()
+            ST_END(st_gen)
         }
+        ST_BEGIN()
+        if (lane == 0) __hip_atomic_store(&rdone[wave], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
+        ST_END(st_bar)
         if (UNI(__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= NW) break;
     }
     if (round >= max_rounds) {
@@ -1242,7 +1322,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
         return;
     }
 #ifdef PWR_STAMPS
-    if (lane == 0) printf("wave%d fast: mailbox %llu cells %llu scan %llu finish %llu n %llu rounds %d\n", wave, fs0, fs1, fs2, fs3, fsn, round);
+    if (lane == 0) printf("wave%d L %d total %llu fast %llu (rows %llu entries %llu) spin %llu (n %llu) general %llu (n %llu) load %llu barrier %llu rounds %d\n", wave, L, (unsigned long long)(ST_NOW() - t_clk0), st_fast, st_rows, st_entries, st_spin, st_spins, st_gen, st_grows, st_load, st_bar, round);
 #endif
     if (tid == 0) {
         m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
@@ -1250,6 +1330,11 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
         m->rounds = round;
         atomicAdd(&st.hdr->cells_computed, m->cells);
     }
+#undef MBP
+#undef MBM
+#undef PTB
+#undef LD64
+#undef ST64
 }
 
 // ---------------------------------------------------------------------------------------------

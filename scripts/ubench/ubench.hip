@@ -1,0 +1,79 @@
+// Issue/latency microbenchmarks for one gfx950 wave (dev tool, not part of the product path).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#define N 512
+#define REP8(x) x x x x x x x x
+#define REP32(x) REP8(x) REP8(x) REP8(x) REP8(x)
+
+__global__ void kb(unsigned long long *out, int *sink, int mode) {
+    __shared__ int lds[256];
+    int lane = threadIdx.x & 63;
+    lds[threadIdx.x & 255] = lane;
+    __syncthreads();
+    int v = lane, w = lane * 3, s = mode;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    if (mode == 0) {          // dependent VALU chain, 32 per iter
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_add_u32 %0, %0, %1" : "+v"(v) : "v"(w));) }
+    } else if (mode == 1) {   // independent VALU pairs
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1" : "+v"(v), "+v"(w));) }
+    } else if (mode == 2) {   // readfirstlane -> salu -> v_mov chain (3 instr)
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_readfirstlane_b32 %1, %0\n s_add_u32 %1, %1, 1\n v_mov_b32 %0, %1" : "+v"(v), "+s"(s) :: "scc");) }
+    } else if (mode == 3) {   // dependent SALU chain
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("s_add_u32 %0, %0, 1" : "+s"(s) :: "scc");) }
+    } else if (mode == 4) {   // taken branch each
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("s_branch 1f\n s_nop 0\n1:\n" ::: "memory");) }
+    } else if (mode == 5) {   // DPP dependent scan step with 2 wait states
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("s_nop 1\n v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(v));) }
+    } else if (mode == 6) {   // lds read dependent chain (pointer chase)
+        int a = (lane * 4) & 1020;
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)\n v_lshlrev_b32 %0, 2, %0" : "+v"(a) :: "memory");) }
+        v = a;
+    } else if (mode == 7) {   // v_cmp -> v_cndmask chain
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_cmp_lt_i32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v) : "v"(w) : "vcc");) }
+    } else if (mode == 8) {   // v_cmp -> s_and_saveexec -> valu -> restore exec
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_cmp_eq_u32 vcc, 63, %1\n s_and_saveexec_b64 s[20:21], vcc\n v_add_u32 %0, %0, 1\n s_mov_b64 exec, s[20:21]" : "+v"(v) : "v"(lane) : "vcc", "s20", "s21");) }
+    } else if (mode == 9) {   // ds_write then ds_read same address, waited (mailbox round trip within wave)
+        int a = lane * 4;
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("ds_write_b32 %1, %0\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)" : "+v"(v) : "v"(a) : "memory");) }
+    } else if (mode == 10) {  // v_readlane -> s_cmp -> s_cbranch not taken
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_readlane_b32 %1, %0, 3\n s_cmp_eq_u32 %1, -7\n s_cbranch_scc1 2f\n v_add_u32 %0, %0, 1\n2:" : "+v"(v), "+s"(s) :: "scc");) }
+    } else if (mode == 11) {  // conditional branch taken via scc (s_cmp; s_cbranch_scc1 taken)
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("s_cmp_eq_u32 %0, %0\n s_cbranch_scc1 3f\n s_nop 0\n3:" :: "s"(s) : "scc");) }
+    } else if (mode == 12) {  // v_min3 dependent
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_min3_i32 %0, %0, %1, %1" : "+v"(v) : "v"(w));) }
+    } else if (mode == 13) {  // s_memtime cost
+        unsigned long long tt;
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("s_memtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(tt));) }
+        v += (int)tt;
+    } else if (mode == 14) {  // s_barrier cost for whatever block size
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("s_barrier" ::: "memory");) }
+    } else if (mode == 15) {  // ds_write lane63 only + waitcnt
+        int a = lane * 4;
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("ds_write_b32 %1, %0\n s_waitcnt lgkmcnt(0)" :: "v"(v), "v"(a) : "memory");) }
+    } else if (mode == 16) {  // v_readfirstlane independent of previous (throughput)
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_readfirstlane_b32 %1, %0" : "+v"(v), "=s"(s));) }
+    } else if (mode == 17) {  // salu->valu: s_add; v_add using sgpr
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("s_add_u32 %1, %1, 1\n v_add_u32 %0, %0, %1" : "+v"(v), "+s"(s) :: "scc");) }
+    }
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
+    sink[threadIdx.x] = v + w + s;
+}
+
+int main() {
+    unsigned long long *d; int *sink; hipMalloc(&d, 64); hipMalloc(&sink, 4096);
+    const char *names[] = {"dep v_add", "2 indep v_add (pair)", "readfirstlane+s_add+v_mov (3)", "dep s_add", "s_branch taken(+skip nop)",
+        "s_nop1 + dpp min", "ds_read chase (+waitcnt+shl)", "v_cmp+v_cndmask (2)", "v_cmp+saveexec+v_add+restore (4)", "ds_write+ds_read+wait (3)",
+        "readlane+s_cmp+cbranch nt+v_add (4)", "s_cmp+cbranch taken (2)", "dep v_min3", "s_memtime+wait", "s_barrier", "ds_write+wait", "indep readfirstlane", "s_add + v_add sgpr (2)"};
+    for (int threads = 64; threads <= 320; threads += 256)
+    for (int m = 0; m < 18; ++m) {
+        hipLaunchKernelGGL(kb, dim3(1), dim3(threads), 0, 0, d, sink, m);
+        hipDeviceSynchronize();
+        hipLaunchKernelGGL(kb, dim3(1), dim3(threads), 0, 0, d, sink, m);
+        unsigned long long h; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+        // s_memtime counts at 100 MHz? report raw ticks per group
+        printf("threads %3d mode %2d %-42s ticks/group %.2f\n", threads, m, names[m], (double)h / (N * 32.0)); fflush(stdout);
+    }
+    return 0;
+}

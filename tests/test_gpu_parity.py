@@ -33,13 +33,11 @@ STEP_CASES = [("toy_a_b1000", 1000, 2), ("toy_a_b50", 50, 2), ("tiny_b10", 10, 3
               ("lowcov_b300", 300, 3), ("edge_shift", 12, 2), ("deep_b200", 200, 1)]
 
 
-@pytest.mark.parametrize("fill", [3, 1, 0], ids=["v2", "wavepipe", "ldsfill"])
-@pytest.mark.parametrize("name,bw,rounds", STEP_CASES, ids=[c[0] for c in STEP_CASES])
-def test_row_by_row_against_oracle(name, bw, rounds, fill, oracle):
+def _row_by_row(name, bw, rounds, oracle, **opts):
     """Every single realignment: same Way, same entry column, same new placement, same MSA."""
     from repeatresolver_amd.realigner import PWReAligner
     rows = split_rows(golden_input(name))
-    g = PWReAligner(rows, bandwidth=bw, fill=fill)
+    g = PWReAligner(rows, bandwidth=bw, **opts)
     g.trim_ends()
     lib = oracle.lib
     h = oracle.create(rows, bw)
@@ -68,6 +66,19 @@ def test_row_by_row_against_oracle(name, bw, rounds, fill, oracle):
         assert g.total_score() == lib.pwo_total_score(h)
     lib.pwo_destroy(h)
     g.close()
+
+
+@pytest.mark.parametrize("fill", [3, 1, 0], ids=["v2", "wavepipe", "ldsfill"])
+@pytest.mark.parametrize("name,bw,rounds", STEP_CASES, ids=[c[0] for c in STEP_CASES])
+def test_row_by_row_against_oracle(name, bw, rounds, fill, oracle):
+    _row_by_row(name, bw, rounds, oracle, fill=fill)
+
+
+@pytest.mark.parametrize("waves", [3, 4, 8, 9])
+@pytest.mark.parametrize("name,bw,rounds", [STEP_CASES[0], STEP_CASES[4], STEP_CASES[6]], ids=["toy_a_b1000", "lowcov_b300", "deep_b200"])
+def test_wave_geometries_row_by_row(name, bw, rounds, waves, oracle):
+    """The other macro-strip widths of the default fill kernel (3/4/8/9 waves per DP)."""
+    _row_by_row(name, bw, rounds, oracle, fill=3, waves=waves)
 
 
 @pytest.mark.parametrize("fill", [3, 1, 0], ids=["v2", "wavepipe", "ldsfill"])
@@ -218,8 +229,8 @@ def test_medium_properties_and_kernel_cross_check():
     from repeatresolver_amd.realigner import PWReAligner
     rows = [bytes(r) for r in dg.make_msa("tree_medium")]
     ref = None
-    for fill, window in ((3, 8), (3, 1), (1, 4)):
-        g = PWReAligner(rows, bandwidth=1000, fill=fill, window=window)
+    for fill, window, waves in ((3, 8, 5), (3, 1, 5), (1, 4, 9), (3, 8, 9), (3, 8, 4)):
+        g = PWReAligner(rows, bandwidth=1000, fill=fill, window=window, waves=waves)
         g.trim_ends()
         before = [r.replace(b"-", b"").replace(b" ", b"") for r in g.export_rows()]
         s0 = g.total_score()
