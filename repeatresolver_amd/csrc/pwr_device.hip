@@ -891,9 +891,9 @@ __global__ __launch_bounds__(NW * 64) void k_fill_wp(DState st, JobBufs jb)
 //   * a wave may retire up to V2_R rows per round (its left neighbour is that far ahead), so the
 //     barrier is amortised; all control state is kept wave-uniform (SGPRs, scalar branches).
 // ---------------------------------------------------------------------------------------------
-#define V2_D 64                                      // mailbox depth (rows); a wave is never more than V2_R rows ahead of its reader
+#define V2_D 128                                     // mailbox depth (rows); a wave is never more than V2_R rows ahead of its reader
 #define V2_PD 512
-#define V2_R 32
+#define V2_R 64
 #define V2_SPINS 256
 #define FBIG 0x3fffffff                              // neutral element of the fast path's min-scan (G + FBIG stays below 2^31)
 #define UNI(v) __builtin_amdgcn_readfirstlane(v)
@@ -1065,7 +1065,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 unsigned mlast_v = (unsigned)LD64(MBM(wl, x - 1));                   // M_last(x-1) of the left neighbour
                 const int y0f = lo + ms * MS;
                 const int rel00 = y0f + lc;
-                // rows this loop may take: up to the last but one of the 64-row block (the general path reloads the
+                // rows this loop may take: up to the last but one of the 64-row block (the general path rotates the
                 // per-block registers), not the last row
                 const int xstop = UNI(min(L - 1, ((blk + 1) << 6) - 1));
                 const int x_in = x;
@@ -1091,6 +1091,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                     if ((cnt | ~(fl << 31)) < 0) break;
                     const int af = __builtin_amdgcn_readlane((int)dca, x & 63);
                     const int Bxf = (int)(db & 0xffffu);
+                    a_prev = af; Bx_prev = Bxf;                                      // for the general path, should it take the next row
                     db = (unsigned)__builtin_amdgcn_readlane((int)dcb, (x + 1) & 63);
                     const int Mleft_v = (fl & 4) ? (int)mlast_v : (int)PWR_INF;
                     const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft_v, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
@@ -1111,13 +1112,14 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                     for (int i = 0; i < C; ++i) sgr[i] = ldsS[wave][cs][min(db >> 16, 3u)][lc + i];
                     // the left neighbour's entry of this row is only needed after the scan: ask for it now, and if it
                     // is not there yet wait for it HERE -- the neighbour is then half a row ahead, not a whole one
-                    unsigned long long fP = LD64(MBP(wl, x)), fM = LD64(MBM(wl, x));
+                    // M first: it is stored last, so its row number vouches for P_end as well
+                    unsigned long long fM = LD64(MBM(wl, x)), fP = LD64(MBP(wl, x));
                     __builtin_amdgcn_sched_barrier(0);
                     const int incl = wave_incl_min(run);
                     const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
                     if (fl & 2) {
                         const unsigned tagx = (unsigned)(x + 1);
-#define V2_BOTH_THERE() (UNI(((unsigned)(fP >> 32) ^ tagx) | ((unsigned)(fM >> 32) ^ tagx)) == 0u)
+#define V2_BOTH_THERE() (UNI((unsigned)(fM >> 32)) == tagx)
                         if (!V2_BOTH_THERE()) {
                             // bounded; gives up at once when the neighbour has left the round (rdone is stored after its
                             // last entry, and LDS keeps one wave's stores in order)
@@ -1127,7 +1129,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                             for (int spin = 0; spin < V2_SPINS; ++spin) {
                                 const int rd = UNI(__hip_atomic_load(&rdone[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                                 __builtin_amdgcn_s_sleep(1);
-                                fP = LD64(MBP(wl, x)); fM = LD64(MBM(wl, x));
+                                fM = LD64(MBM(wl, x)); fP = LD64(MBP(wl, x));
                                 if (V2_BOTH_THERE() || rd == round + 1) break;
                             }
 #ifdef PWR_STAMPS
@@ -1179,8 +1181,6 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 }
                 if (x != x_in) {                                                     // resynchronise the general path's row state
                     nacc = x & 15;
-                    const int apw = __builtin_amdgcn_readlane(wcur, (x - 1) & 63);
-                    a_prev = max(0, apw - H); Bx_prev = min(B, W - a_prev);
                     a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
                     sx = __builtin_amdgcn_readlane(scur, x & 63);
                 }
