@@ -955,6 +955,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     __shared__ int rdone[NW];                       // round + 1 once wave w has left that round
     __shared__ int s_done;
 #define LD64(REF) __hip_atomic_load(&(REF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LD32LO(REF) __hip_atomic_load((unsigned *)&(REF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)   /* value half */
 #define ST64(REF, VAL, TAG) __hip_atomic_store(&(REF), ((unsigned long long)(unsigned)(TAG) << 32) | (unsigned)(VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define MBP(W_, X_) mbQ[2 * ((W_) * V2_D + ((X_) & (V2_D - 1)))]
 #define MBM(W_, X_) mbQ[2 * ((W_) * V2_D + ((X_) & (V2_D - 1))) + 1]
@@ -1112,8 +1113,10 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                     for (int i = 0; i < C; ++i) sgr[i] = ldsS[wave][cs][min(db >> 16, 3u)][lc + i];
                     // the left neighbour's entry of this row is only needed after the scan: ask for it now, and if it
                     // is not there yet wait for it HERE -- the neighbour is then half a row ahead, not a whole one
-                    // M first: it is stored last, so its row number vouches for P_end as well
-                    unsigned long long fM = LD64(MBM(wl, x)), fP = LD64(MBP(wl, x));
+                    // M first: it is stored last, so its row number vouches for P_end as well (of which only the value
+                    // half is read)
+                    unsigned long long fM = LD64(MBM(wl, x));
+                    unsigned fP = LD32LO(MBP(wl, x));
                     __builtin_amdgcn_sched_barrier(0);
                     const int incl = wave_incl_min(run);
                     const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
@@ -1129,7 +1132,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                             for (int spin = 0; spin < V2_SPINS; ++spin) {
                                 const int rd = UNI(__hip_atomic_load(&rdone[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                                 __builtin_amdgcn_s_sleep(1);
-                                fM = LD64(MBM(wl, x)); fP = LD64(MBP(wl, x));
+                                fM = LD64(MBM(wl, x)); fP = LD32LO(MBP(wl, x));
                                 if (V2_BOTH_THERE() || rd == round + 1) break;
                             }
 #ifdef PWR_STAMPS
@@ -1140,7 +1143,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 #undef V2_BOTH_THERE
                     }
                     if (!bail) {
-                        const int P_in_v = (fl & 2) ? (int)(unsigned)fP : PWR_BIG;
+                        const int P_in_v = (fl & 2) ? (int)fP : PWR_BIG;
                         const int P_end_v = min(P_in_v, incl);                       // lane 63: the row's running minimum so far
                         // cells left of the band come before its first cell in scan order, so their p is still the
                         // neutral element FBIG = 2^30 - 1 and G + p lands at or above INF by itself; the min keeps it there
@@ -1334,6 +1337,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 #undef MBM
 #undef PTB
 #undef LD64
+#undef LD32LO
 #undef ST64
 }
 
