@@ -1109,16 +1109,39 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                         tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bxf) ? t3 : FBIG;
                         run = min(run, tg[i]);
                     }
-#pragma unroll
-                    for (int i = 0; i < C; ++i) sgr[i] = ldsS[wave][cs][min(db >> 16, 3u)][lc + i];
-                    // the left neighbour's entry of this row is only needed after the scan: ask for it now, and if it
-                    // is not there yet wait for it HERE -- the neighbour is then half a row ahead, not a whole one
+                    // The left neighbour's words of this row are only needed after the scan: ask for them now, and if they
+                    // are not there yet wait for them THERE -- the neighbour is then half a row ahead, not a whole one.
                     // M first: it is stored last, so its row number vouches for P_end as well (of which only the value
-                    // half is read)
+                    // half is read).
                     unsigned long long fM = LD64(MBM(wl, x));
                     unsigned fP = LD32LO(MBP(wl, x));
                     __builtin_amdgcn_sched_barrier(0);
-                    const int incl = wave_incl_min(run);
+                    // The scan: six dependent DPP steps, each of which must be two issue slots behind the one before.
+                    // Those slots are filled by hand with work that does not depend on it: the fetch of the next row's
+                    // substitution column, and where / under which row number this row will be published.
+#define V2_SCAN_STEP(CTRL, RMASK) { const int t_ = __builtin_amdgcn_update_dpp(PWR_BIG, incl, CTRL, RMASK, 0xF, false); incl = min(incl, t_); }
+#define V2_FENCE() __builtin_amdgcn_sched_barrier(0)
+                    int incl = run;
+                    V2_SCAN_STEP(DPP_ROW_SHR(1), 0xF) V2_FENCE();
+                    const unsigned sxn = min(db >> 16, 3u);
+                    V2_FENCE(); V2_SCAN_STEP(DPP_ROW_SHR(2), 0xF) V2_FENCE();
+                    const int *const srow = &ldsS[wave][cs][sxn][lc];
+                    const int qs = wave * V2_D + (x & (V2_D - 1));
+                    V2_FENCE(); V2_SCAN_STEP(DPP_ROW_SHR(4), 0xF) V2_FENCE();
+#pragma unroll
+                    for (int i = 0; i < C; ++i) sgr[i] = srow[i];
+                    int qi = lane == 63 ? qs : mb_dump;
+                    asm volatile("" : "+v"(qi));                                     // (keeps the select in this slot)
+                    V2_FENCE(); V2_SCAN_STEP(DPP_ROW_SHR(8), 0xF) V2_FENCE();
+                    unsigned qoff = (unsigned)qi * 16u;                              // byte offset of the two words in mbQ
+                    asm volatile("" : "+v"(qoff));
+                    unsigned long long *const qp = (unsigned long long *)((char *)mbQ + qoff);
+                    V2_FENCE(); V2_SCAN_STEP(DPP_ROW_BCAST15, 0xA) V2_FENCE();
+                    const unsigned long long tagw = (unsigned long long)(unsigned)(x + 1) << 32;
+                    asm volatile("" :: "v"((unsigned)(tagw >> 32)));
+                    V2_FENCE(); V2_SCAN_STEP(DPP_ROW_BCAST31, 0xC) V2_FENCE();
+#undef V2_SCAN_STEP
+#undef V2_FENCE
                     const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
                     if (fl & 2) {
                         const unsigned tagx = (unsigned)(x + 1);
@@ -1156,11 +1179,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                         }
                         mlast_v = (unsigned)fM;                                      // valid whenever the next row needs it
                         ++x; --cnt;
-                        {
-                            const int qi = lane == 63 ? wave * V2_D + ((x - 1) & (V2_D - 1)) : mb_dump;
-                            ST64(mbQ[2 * qi], P_end_v, x);
-                            ST64(mbQ[2 * qi + 1], Mprev[C - 1], x);
-                        }
+                        __hip_atomic_store(qp, tagw | (unsigned)P_end_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(qp + 1, tagw | Mprev[C - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (fl & 8)                                                  // the band ends in this macro-strip
                             ST64(ptQ[lane == 63 ? ((x - 1) & (V2_PD - 1)) : pt_dump], P_end_v, x);
                         if ((x & 15) == 0) {                                         // the 16-row group is complete
