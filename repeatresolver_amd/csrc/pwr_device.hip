@@ -927,7 +927,7 @@ __device__ __forceinline__ unsigned acc_push(unsigned acc, unsigned long long ma
 
 #ifdef PWR_STAMPS
 #define ST_NOW() __builtin_amdgcn_s_memtime()
-#define ST_DECL unsigned long long st_fast = 0, st_spin = 0, st_gen = 0, st_bar = 0, st_load = 0, st_t = 0, st_rows = 0, st_entries = 0, st_spins = 0, st_grows = 0;
+#define ST_DECL unsigned long long st_gwait = 0, st_nowork = 0, st_gw0 = 0, st_fast = 0, st_spin = 0, st_gen = 0, st_bar = 0, st_load = 0, st_t = 0, st_rows = 0, st_entries = 0, st_spins = 0, st_grows = 0;
 #define ST_BEGIN() st_t = ST_NOW();
 #define ST_END(ACC) ACC += ST_NOW() - st_t;
 #else
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     uint4 d4 = desc[min(lane, L - 1)];
     unsigned dca = d4.x, dcb = d4.y, dcf = (wave < 8 ? d4.z : d4.w) >> fsh;
     d4 = desc[min(64 + lane, L - 1)];
-    unsigned dna = d4.x, dnb = d4.y, dnf = (wave < 8 ? d4.z : d4.w) >> fsh;
+    unsigned dna = d4.x, dnb = d4.y, dnz = d4.z, dnw = d4.w;        // (flags picked when the block becomes current: no wait on the load here)
     int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H), a_prev = 0, Bx_prev = 0;
     int sx = __builtin_amdgcn_readlane(scur, 0);
     const int max_rounds = 4 * L + 64 * NW + 1024;
@@ -1034,11 +1034,11 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
         if (x < L) {                                                                             \
             if ((x >> 6) != blk) {                                                               \
                 blk = x >> 6;                                                                    \
-                wcur = wnxt; scur = snxt; dca = dna; dcb = dnb; dcf = dnf;                       \
+                wcur = wnxt; scur = snxt; dca = dna; dcb = dnb; dcf = (wave < 8 ? dnz : dnw) >> fsh; \
                 wnxt = way[min(x + 64 + lane, L - 1)];                                           \
                 snxt = seq[min(x + 64 + lane, L - 1)];                                           \
                 { const uint4 e4_ = desc[min(x + 64 + lane, L - 1)];                             \
-                  dna = e4_.x; dnb = e4_.y; dnf = (wave < 8 ? e4_.z : e4_.w) >> fsh; }           \
+                  dna = e4_.x; dnb = e4_.y; dnz = e4_.z; dnw = e4_.w; }                          \
             }                                                                                    \
             a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);                             \
             sx = __builtin_amdgcn_readlane(scur, x & 63);                                        \
@@ -1062,7 +1062,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
             //      every lane the same value), lane 63 publishes by index, and the row's substitution column comes
             //      from the LDS table -- no EXEC changes, no scalar round trips, one exit test.
             bool not_ready = false;
-            if ((x >> 4) == gacc && ran_prev) {
+            if (ran_prev) {
+                if ((x >> 4) != gacc) { V2_FLUSH() gacc = x >> 4; }
                 unsigned mlast_v = (unsigned)LD64(MBM(wl, x - 1));                   // M_last(x-1) of the left neighbour
                 const int y0f = lo + ms * MS;
                 const int rel00 = y0f + lc;
@@ -1085,15 +1086,12 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 #ifdef PWR_STAMPS
                 ++st_entries; const unsigned long long st_f0 = ST_NOW(); unsigned long long st_sp = 0;
 #endif
-                while (true) {
-                    x = UNI(x); cnt = UNI(cnt); gacc = UNI(gacc); db = UNI(db); bail = UNI(bail);
-                    const int fl = __builtin_amdgcn_readlane((int)dcf, x & 63);
-                    // one exit test (sign bits): no rows left (or the row before gave up) / not an ordinary row (bit 0 clear)
-                    if ((cnt | ~(fl << 31)) < 0) break;
+                // One ordinary row.  fl = its flags, dbn = the {Bx, base} descriptor word of the row after it.
+                auto fast_row = [&](const int fl, const unsigned dbn) __attribute__((always_inline)) {
                     const int af = __builtin_amdgcn_readlane((int)dca, x & 63);
                     const int Bxf = (int)(db & 0xffffu);
                     a_prev = af; Bx_prev = Bxf;                                      // for the general path, should it take the next row
-                    db = (unsigned)__builtin_amdgcn_readlane((int)dcb, (x + 1) & 63);
+                    db = dbn;
                     const int Mleft_v = (fl & 4) ? (int)mlast_v : (int)PWR_INF;
                     const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft_v, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
                     const int rel0 = rel00 - af;
@@ -1192,6 +1190,30 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                     } else {
                         cnt = -1;                                // the neighbour will not post row x in this round
                     }
+                };
+                while (true) {
+                    x = UNI(x); cnt = UNI(cnt); gacc = UNI(gacc); db = UNI(db); bail = UNI(bail);
+                    const int fl = __builtin_amdgcn_readlane((int)dcf, x & 63);
+                    // one exit test (sign bits): no rows left (or the row before gave up) / not an ordinary row (bit 0 clear)
+                    if ((cnt | ~(fl << 31)) < 0) break;
+                    fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dcb, (x + 1) & 63));
+                }
+                // The last row of a 64-row block, if it is an ordinary one as well: its successor's descriptor is in the
+                // registers of the next block, which then become the current ones (as in V2_NEXT_ROW).
+                if (!bail && budget - (x - x_in) > 0 && (x & 63) == 63 && x < L - 1) {
+                    const int fl = __builtin_amdgcn_readlane((int)dcf, 63);
+                    if (fl & 1) {
+                        cnt = 0;
+                        fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dnb, 0));
+                        if (!bail) {
+                            blk = x >> 6;
+                            wcur = wnxt; scur = snxt; dca = dna; dcb = dnb; dcf = (wave < 8 ? dnz : dnw) >> fsh;
+                            wnxt = way[min(x + 64 + lane, L - 1)];
+                            snxt = seq[min(x + 64 + lane, L - 1)];
+                            const uint4 e4_ = desc[min(x + 64 + lane, L - 1)];
+                            dna = e4_.x; dnb = e4_.y; dnz = e4_.z; dnw = e4_.w;
+                        }
+                    }
                 }
 #ifdef PWR_STAMPS
                 st_fast += ST_NOW() - st_f0 - st_sp; st_spin += st_sp; st_rows += x - x_in;
@@ -1238,6 +1260,9 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
             if (ms > ms_hi) {                               // no work for this wave in row x
                 ran_prev = 0;
                 V2_NEXT_ROW()
+#ifdef PWR_STAMPS
+                ++st_nowork;
+#endif
                 ST_END(st_gen)
                 continue;
             }
@@ -1251,6 +1276,9 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
             // has left the round (rdone is stored after its last entry, LDS keeps one wave's stores in order)
             unsigned ePx = 0, ePy = 0, eMy = 0, eTx = 0;
             bool ready = false;
+#ifdef PWR_STAMPS
+            st_gw0 = ST_NOW();
+#endif
             for (int spin = 0; spin < V2_SPINS; ++spin) {
                 const int rd = UNI(__hip_atomic_load(&rdone[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (spin) __builtin_amdgcn_s_sleep(1);
@@ -1263,6 +1291,9 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                         (!needM || UNI((unsigned)(eM >> 32)) == (unsigned)x) && (!needT || UNI((unsigned)(eT >> 32)) == (unsigned)x);
                 if (ready || rd == round + 1) break;
             }
+#ifdef PWR_STAMPS
+            st_gwait += ST_NOW() - st_gw0;
+#endif
             if (!ready) { ST_END(st_gen) break; }
             --budget;
             int Mleft = (int)PWR_INF;
@@ -1345,7 +1376,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
         return;
     }
 #ifdef PWR_STAMPS
-    if (lane == 0) printf("wave%d L %d total %llu fast %llu (rows %llu entries %llu) spin %llu (n %llu) general %llu (n %llu) load %llu barrier %llu rounds %d\n", wave, L, (unsigned long long)(ST_NOW() - t_clk0), st_fast, st_rows, st_entries, st_spin, st_spins, st_gen, st_grows, st_load, st_bar, round);
+    if (lane == 0) printf("wave%d L %d total %llu fast %llu (rows %llu entries %llu) spin %llu (n %llu) general %llu (n %llu, no-work %llu, waiting %llu) load %llu barrier %llu rounds %d\n", wave, L, (unsigned long long)(ST_NOW() - t_clk0), st_fast, st_rows, st_entries, st_spin, st_spins, st_gen, st_grows, st_nowork, st_gwait, st_load, st_bar, round);
 #endif
     if (tid == 0) {
         m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
