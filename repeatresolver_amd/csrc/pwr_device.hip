@@ -57,7 +57,8 @@ struct JobMeta {                   // 64 B
     unsigned long long cells;
     int slot_lo, slot_hi;          // column slots at both ends of the gathered interval
     unsigned clk, rclk;            // fill kernel duration in shader clocks / 100 MHz ticks (diagnostic)
-    int rounds, pad1;              // lock-step rounds the fill needed (diagnostic)
+    int rounds;                    // lock-step rounds the fill needed (diagnostic)
+    int abort;                     // k_fill_v3: a wave gave up waiting; its siblings leave too
 };
 
 struct DState {
@@ -91,6 +92,11 @@ struct JobBufs {
     uint4 *desc;                   // [njobs][Lmax]   per DP row: {anf, Bx | base << 16, wave flags 0-7, wave flags 8-15} (k_fill_v2)
     int wpNW, wpMS;                // geometry of the wave pipeline the descriptors are made for
     unsigned *lastM;               // [njobs][NC]     scores of the last DP row (wave-pipeline fill)
+    unsigned long long *gmb;       // [njobs][NW][Lmax][2] k_fill_v3: {P_end, tag}, {M_last, tag} per wave and DP row
+    unsigned long long *gpt;       // [njobs][Lmax]   k_fill_v3: {Ptot, tag} per DP row
+    unsigned long long *gprog;     // [njobs][NW]     k_fill_v3: {rows a wave is done with, tag of row 0}
+    unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
+    int njobs_launched;
     int layout;                    // 0: dirs indexed by band cell (y - anf(x)); 1: by (y - lo) mod NC
     int Lmax, colcap, NC;
     size_t dirstride;
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         unsigned long long U = 0;
         for (int w = 0; w < GATHER_NT / 64; ++w) U += s_u[w];
         const unsigned long long bound = U + (unsigned long long)mx * (unsigned long long)(2 * B + 4096);
-        m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx;
+        m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx; m->abort = 0;
         unsigned long long cs = 0;
         for (int w = 0; w < GATHER_NT / 64; ++w) cs += s_cells[w];
         m->cells = cs; m->ver = st.hdr->version; m->slot_lo = order[lo]; m->slot_hi = order[hi];
@@ -1393,6 +1399,515 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 }
 
 // ---------------------------------------------------------------------------------------------
+// fill v3: the same wave pipeline as k_fill_v2, spread over compute units.  Every wave of a DP is its own
+// 64-thread work-group, so each gets a SIMD to itself (in k_fill_v2 the fifth wave of a work-group shares one,
+// and that pair sets the pace); the grid is (8, NW, jobs / 8) so that the NW waves of one DP land on the same
+// XCD and talk through its L2.  What a wave publishes per DP row goes to global memory:
+//   gmb[(w * Lmax + x) * 2 + 0]  {P_end, tag}   the running minimum its right neighbour continues
+//   gmb[(w * Lmax + x) * 2 + 1]  {M_last, tag}  the score of its last column
+//   gpt[x]                       {Ptot, tag}    the minimum of the whole row (posted by the wave that ends the band)
+// each one aligned 64-bit word, stored and loaded whole (relaxed agent-scope atomics) and self-validating:
+// tag = launch epoch << 17 | row + 1, so nothing has to be cleared between launches.  There are no rounds and no
+// barriers: a wave simply runs down its rows.  It reads its left neighbour's words sixteen rows at a time (lane
+// l of a register pair holds row 16 g + l, fetched while group g - 1 is computed, consumed with v_readlane), so
+// in the steady state it trails the neighbour by a group or two and never waits; when a word is not there yet it
+// takes the row back, re-reads the group until it is (bounded: a time-out flags the job) and goes on.
+// Dependencies only point to the left neighbour, whose own never point back, so this cannot deadlock as long as
+// all NW work-groups are resident -- NW <= 9 waves per DP and at most a few dozen DPs per launch on 256 CUs.
+// ---------------------------------------------------------------------------------------------
+#ifdef PWR_STAMPS
+#define V3_SAY(N) if (lane == 0) printf("v3 timeout #%d: job %d wave %d x %d L %d\n", N, job, wave, x, L);
+#else
+#define V3_SAY(N)
+#endif
+#define V3_G 16                                      // rows per mailbox register group (= rows per traceback word)
+#define V3_TIMEOUT (1ull << 31)                      // shader clocks (about a second) a wave waits for its neighbour
+
+template <int NW, int C>
+__global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
+{
+#ifdef PWR_STAMPS
+    unsigned long long s3_fast = 0, s3_bailwait = 0, s3_pace = 0, s3_gen = 0, s3_genwait = 0, s3_rows = 0, s3_bails = 0, s3_entries = 0, s3_t = 0, s3_mlast = 0;
+#endif
+    constexpr int MS = 64 * C, RS = NW * MS;
+    __shared__ __attribute__((aligned(16))) int ldsS1[2][4][MS];
+    const int job = blockIdx.x + 8 * blockIdx.z, lane = threadIdx.x;
+    const int wave = blockIdx.y;
+    if (job >= jb.njobs_launched) return;
+    JobMeta *m = &jb.meta[job];
+    const int L = UNI(m->L);
+    if (L <= 0 || !m->ok) return;
+    const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
+
+    const int lo = UNI(m->lo), hi = UNI(m->hi), W = UNI(m->W), B = st.B, H = st.H;
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const uint8_t *seq = st.seq + st.rowoff[UNI(m->k)];
+    const int4 *rec2 = jb.rec2 + (size_t)job * jb.colcap * 2;
+    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+    unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
+    const int wl = (wave + NW - 1) % NW;
+    const int lc = lane * C;
+    const unsigned tagbase = jb.tagbase;
+    unsigned long long *const gmy = jb.gmb + ((size_t)job * NW + wave) * (size_t)jb.Lmax * 2;      // this wave's words
+    const unsigned long long *const gleftw = jb.gmb + ((size_t)job * NW + wl) * (size_t)jb.Lmax * 2;   // the left neighbour's
+    unsigned long long *const gpt = jb.gpt + (size_t)job * jb.Lmax;
+    unsigned long long *const gprog = jb.gprog + (size_t)job * 16;
+    int *const abortf = &m->abort;
+#define GLD(PTR) __hip_atomic_load((PTR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GST(PTR, VAL, ROW) __hip_atomic_store((PTR), ((unsigned long long)(tagbase | (unsigned)((ROW) + 1)) << 32) | (unsigned)(VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define TAGOF(W64) ((unsigned)((W64) >> 32))
+#define V3_LOADS(MSX, SLOT, AU, AG, AI, GL)                                                      \
+    {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < C; ++i) {                                          \
+            const int y_ = lo + (MSX) * MS + lc + i;                                             \
+            int4 p_ = make_int4(PWR_BIG / 2, PWR_BIG / 2, PWR_BIG / 2, PWR_BIG / 2);             \
+            int4 q_ = make_int4(PWR_BIG / 2, 0, PWR_BIG / 2, 0);                                 \
+            if (y_ <= hi) { p_ = rec2[2 * (y_ - lo)]; q_ = rec2[2 * (y_ - lo) + 1]; }            \
+            ldsS1[SLOT][0][lc + i] = p_.x; ldsS1[SLOT][1][lc + i] = p_.y;                        \
+            ldsS1[SLOT][2][lc + i] = p_.z; ldsS1[SLOT][3][lc + i] = p_.w;                        \
+            AU[i] = q_.x; AG[i] = q_.y; AI[i] = q_.z;                                            \
+        }                                                                                        \
+        const int yq_ = lo + (MSX) * MS - 1;                                                     \
+        GL = (yq_ >= lo && yq_ <= hi) ? UNI(rec2[2 * (yq_ - lo) + 1].y) : 0;                     \
+    }
+
+    int ug[C], gg[C], ig[C];
+    int nu[C], ng[C], ni[C];
+    int gleft = 0, gleftn = 0;
+    int ms = wave, msn = wave + NW;
+    int cs = 0;
+    V3_LOADS(ms, 0, ug, gg, ig, gleft)
+    V3_LOADS(msn, 1, nu, ng, ni, gleftn)
+
+    unsigned Mprev[C], accA[C], accC[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) { Mprev[i] = 0; accA[i] = accC[i] = 0; }
+    int gacc = -1, nacc = 0;
+    int ran_prev = 0;
+    int x = 0, blk = 0;
+    int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
+    int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
+    const uint4 *desc = jb.desc + (size_t)job * jb.Lmax;
+    const int fsh = 4 * (wave & 7);
+    uint4 d4 = desc[min(lane, L - 1)];
+    unsigned dca = d4.x, dcb = d4.y, dcf = (wave < 8 ? d4.z : d4.w) >> fsh;
+    d4 = desc[min(64 + lane, L - 1)];
+    unsigned dna = d4.x, dnb = d4.y, dnz = d4.z, dnw = d4.w;
+    int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H), a_prev = 0, Bx_prev = 0;
+    int sx = __builtin_amdgcn_readlane(scur, 0);
+
+    // the left neighbour's words of row group cg (lane l: row V3_G * cg + l; lanes 16.. repeat) and of group cg + 1
+    unsigned long long cP = 0, cM = 0, nP = 0, nM = 0;
+    int cg = -2;
+    unsigned pm15 = 0, pm15t = 0;                          // {M_last, tag} of the last row of group cg - 1
+#define V3_LOAD_GROUP(G_, QP, QM)                                                                \
+    {                                                                                            \
+        const int r_ = min((G_) * V3_G + (lane & (V3_G - 1)), L - 1);                            \
+        QP = GLD(gleftw + 2 * (size_t)r_); QM = GLD(gleftw + 2 * (size_t)r_ + 1);               \
+    }
+#define V3_ALIGN_ACC(WANT)                                                                       \
+    if (nacc != (WANT)) {                                                                        \
+        const int sh_ = (WANT) - nacc;                                                           \
+        _Pragma("unroll") for (int i = 0; i < C; ++i) { accA[i] <<= sh_; accC[i] <<= sh_; }      \
+        nacc = (WANT);                                                                           \
+    }
+#define V3_FLUSH()                                                                               \
+    if (gacc >= 0) {                                                                             \
+        V3_ALIGN_ACC(16)                                                                         \
+        uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;                \
+        _Pragma("unroll") for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; } \
+        gacc = -1; nacc = 0;                                                                     \
+    }
+#define V3_ROTATE_BLOCK()                                                                        \
+    {                                                                                            \
+        blk = x >> 6;                                                                            \
+        wcur = wnxt; scur = snxt; dca = dna; dcb = dnb; dcf = (wave < 8 ? dnz : dnw) >> fsh;     \
+        wnxt = way[min(x + 64 + lane, L - 1)];                                                   \
+        snxt = seq[min(x + 64 + lane, L - 1)];                                                   \
+        const uint4 e4_ = desc[min(x + 64 + lane, L - 1)];                                       \
+        dna = e4_.x; dnb = e4_.y; dnz = e4_.z; dnw = e4_.w;                                      \
+    }
+#define V3_NEXT_ROW()                                                                            \
+    {                                                                                            \
+        a_prev = a; Bx_prev = Bx;                                                                \
+        ++x;                                                                                     \
+        if (lane == 0) GST(gprog + wave, x, 0);                                                  \
+        if (x < L) {                                                                             \
+            if ((x >> 6) != blk) V3_ROTATE_BLOCK()                                               \
+            a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);                             \
+            sx = __builtin_amdgcn_readlane(scur, x & 63);                                        \
+        }                                                                                        \
+    }
+
+    bool dead = false;
+    while (x < L && !dead) {
+        ran_prev = UNI(ran_prev); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); ms = UNI(ms); cs = UNI(cs); gleft = UNI(gleft); cg = UNI(cg);
+        x = UNI(x);
+        // ---- fast path: runs of ordinary rows (flagged by the gather), at most one 16-row group per trip
+        if (ran_prev && x < L - 1) {
+#ifdef PWR_STAMPS
+            ++s3_entries; const unsigned long long s3_f0 = __builtin_amdgcn_s_memtime(); unsigned long long s3_w = 0;
+#endif
+            if ((x >> 4) != gacc) { V3_FLUSH() gacc = x >> 4; }
+            const int g = x >> 4;
+            if (cg != g) {                                                       // bring the mailbox registers to group g
+                if (cg + 1 == g) {
+                    pm15 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cM, V3_G - 1);
+                    pm15t = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cM), V3_G - 1);
+                    cP = nP; cM = nM;
+                } else {
+                    pm15t = 0;
+                    V3_LOAD_GROUP(g, cP, cM)
+                }
+                cg = g;
+                V3_LOAD_GROUP(g + 1, nP, nM)
+            }
+            const int y0f = lo + ms * MS;
+            const int rel00 = y0f + lc;
+            // rows this trip may take: to the end of the 16-row group, not the last row of a 64-row block (that one
+            // follows below, it needs the next block's registers), not the last row
+            const int xstop = UNI(min(min(L - 1, ((blk + 1) << 6) - 1), (g + 1) << 4));
+            const int x_in = x;
+            V3_ALIGN_ACC(x & 15)
+            unsigned db = (unsigned)__builtin_amdgcn_readlane((int)dcb, x & 63);
+            int sgr[C];
+#pragma unroll
+            for (int i = 0; i < C; ++i) sgr[i] = ldsS1[cs][min(db >> 16, 3u)][lc + i];
+            // M_last(x-1) of the left neighbour, if row x wants it: it was posted together with the P_end this wave
+            // consumed in row x-1, so it is in the group registers (or, for the first row of a group, was saved from the
+            // previous group's); only after a detour through the general path may it have to come from memory
+            int mlast = (int)PWR_INF;
+            {
+                const int fl0 = __builtin_amdgcn_readlane((int)dcf, x & 63);
+                if ((fl0 & 5) == 5) {
+                    const unsigned want = tagbase | (unsigned)x;
+                    unsigned v_ = pm15, t_ = pm15t;
+                    if (x & (V3_G - 1)) {
+                        v_ = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cM, (x - 1) & (V3_G - 1));
+                        t_ = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cM), (x - 1) & (V3_G - 1));
+                    }
+                    if (t_ != want) {
+                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                        while (true) {
+                            const unsigned long long w_ = GLD(gleftw + 2 * (size_t)(x - 1) + 1);
+                            v_ = UNI((unsigned)w_);
+                            if (UNI(TAGOF(w_)) == want) break;
+                            if (UNI(GLD(abortf)) || __builtin_amdgcn_s_memtime() - t0 > V3_TIMEOUT) { dead = true; V3_SAY(1) break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                    mlast = (int)v_;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < C; ++i) asm volatile("" : "+v"(sgr[i]));
+            int cnt = xstop - x - 1;
+            int bail = dead ? 1 : 0;
+            if (dead) cnt = -1;
+            // One ordinary row.  fl = its flags, dbn = the {Bx, base} descriptor word of the row after it.
+            auto fast_row = [&](const int fl, const unsigned dbn) __attribute__((always_inline)) {
+                const int af = __builtin_amdgcn_readlane((int)dca, x & 63);
+                const int Bxf = (int)(db & 0xffffu);
+                a_prev = af; Bx_prev = Bxf;
+                db = dbn;
+                const int Mleft = (fl & 4) ? mlast : (int)PWR_INF;
+                const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+                const int rel0 = rel00 - af;
+                int tg[C];
+                int run = FBIG;
+#pragma unroll
+                for (int i = 0; i < C; ++i) {
+                    const int pm1 = i ? (int)Mprev[i > 0 ? i - 1 : 0] : pm1_0;
+                    const int d = pm1 + sgr[i];
+                    const int u = (int)Mprev[i] + ug[i];
+                    accC[i] = acc_push(accC[i], __builtin_amdgcn_sicmp(d, u, ICMP_SLE));
+                    const int t3 = min(min(d, u), ig[i]);
+                    tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bxf) ? t3 : FBIG;
+                    run = min(run, tg[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // The scan: six dependent DPP steps, each two issue slots behind the one before; the slots are filled by
+                // hand with the fetch of the next row's substitution column and the neighbour's words of this row.
+#define V3_SCAN_STEP(CTRL, RMASK) { const int t_ = __builtin_amdgcn_update_dpp(PWR_BIG, incl, CTRL, RMASK, 0xF, false); incl = min(incl, t_); }
+#define V3_FENCE() __builtin_amdgcn_sched_barrier(0)
+                int incl = run;
+                V3_SCAN_STEP(DPP_ROW_SHR(1), 0xF) V3_FENCE();
+                const unsigned sxn = min(db >> 16, 3u);
+                const int *const srow = &ldsS1[cs][sxn][lc];
+                V3_FENCE(); V3_SCAN_STEP(DPP_ROW_SHR(2), 0xF) V3_FENCE();
+#pragma unroll
+                for (int i = 0; i < C; ++i) sgr[i] = srow[i];
+                const unsigned pval = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cP, x & (V3_G - 1));
+                V3_FENCE(); V3_SCAN_STEP(DPP_ROW_SHR(4), 0xF) V3_FENCE();
+                const unsigned ptag = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cP), x & (V3_G - 1));
+                const unsigned mval = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cM, x & (V3_G - 1));
+                V3_FENCE(); V3_SCAN_STEP(DPP_ROW_SHR(8), 0xF) V3_FENCE();
+                const unsigned mtag = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cM), x & (V3_G - 1));
+                const unsigned tagx = tagbase | (unsigned)(x + 1);
+                V3_FENCE(); V3_SCAN_STEP(DPP_ROW_BCAST15, 0xA) V3_FENCE();
+                const unsigned miss = (fl & 2) ? ((ptag ^ tagx) | (mtag ^ tagx)) : 0u;
+                V3_FENCE(); V3_SCAN_STEP(DPP_ROW_BCAST31, 0xC) V3_FENCE();
+#undef V3_SCAN_STEP
+#undef V3_FENCE
+                const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
+                if (miss == 0u) {
+                    const int P_in = (fl & 2) ? (int)pval : PWR_BIG;
+                    const int P_end_v = min(P_in, incl);                             // lane 63: the row's running minimum so far
+                    int p = min(min(P_in, excl), FBIG);
+#pragma unroll
+                    for (int i = 0; i < C; ++i) {
+                        accA[i] = acc_push(accA[i], __builtin_amdgcn_sicmp(tg[i], p, ICMP_SGE));
+                        p = min(p, tg[i]);
+                        Mprev[i] = min((unsigned)(gg[i] + p), PWR_INF);
+                    }
+                    mlast = (int)mval;                                               // valid whenever the next row needs it
+                    if (lane == 63) {
+                        GST(gmy + 2 * (size_t)x, P_end_v, x);
+                        GST(gmy + 2 * (size_t)x + 1, Mprev[C - 1], x);
+                        if (fl & 8) GST(gpt + x, P_end_v, x);                        // the band ends in this macro-strip
+                    }
+                    ++x; --cnt;
+                } else {
+                    bail = 1; cnt = -1;                                              // the neighbour's row x is not there yet
+                }
+            };
+            while (true) {
+                x = UNI(x); cnt = UNI(cnt); db = UNI(db); bail = UNI(bail); mlast = UNI(mlast);
+                const int fl = __builtin_amdgcn_readlane((int)dcf, x & 63);
+                if ((cnt | ~(fl << 31)) < 0) break;
+                fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dcb, (x + 1) & 63));
+            }
+            // the last row of a 64-row block (its successor's descriptor is in the next block's registers)
+            if (!bail && (x & 63) == 63 && x < L - 1) {
+                const int fl = __builtin_amdgcn_readlane((int)dcf, 63);
+                if (fl & 1) {
+                    cnt = 0;
+                    fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dnb, 0));
+                    if (!bail) V3_ROTATE_BLOCK()
+                }
+            }
+#ifdef PWR_STAMPS
+            const unsigned long long s3_b0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (bail && !dead) {
+#ifdef PWR_STAMPS
+                ++s3_bails;
+#endif
+                // take the unfinished row back, then re-read the group until the neighbour's row x is there
+#pragma unroll
+                for (int i = 0; i < C; ++i) accC[i] >>= 1;
+                const unsigned want = tagbase | (unsigned)(x + 1);
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                while (true) {
+                    V3_LOAD_GROUP(g, cP, cM)
+                    const unsigned tp = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cP), x & (V3_G - 1));
+                    const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cM), x & (V3_G - 1));
+                    if (tp == want && tm == want) break;
+                    if (UNI(GLD(abortf)) || __builtin_amdgcn_s_memtime() - t0 > V3_TIMEOUT) { dead = true; V3_SAY(2) break; }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+#ifdef PWR_STAMPS
+                s3_bailwait += __builtin_amdgcn_s_memtime() - s3_b0;
+                const unsigned long long s3_p0 = __builtin_amdgcn_s_memtime();
+#endif
+                // Pacing: go on only when the neighbour is two groups ahead (or done), so that from here on the group
+                // fetched one group early is complete when it arrives -- but only while the neighbour advances: in the
+                // ring it may itself be waiting for this wave (it was the leader, its macro-strip left the band, and its
+                // new one at the far end depends on everybody else), and then there is nothing to wait for.
+                const unsigned need = (unsigned)min(((g + 2) << 4) + 8, L);
+                unsigned seen = 0;
+                unsigned long long t_seen = __builtin_amdgcn_s_memtime();
+                while (!dead) {
+                    const unsigned long long pw = GLD(gprog + wl);
+                    const unsigned have = UNI(TAGOF(pw)) == (tagbase | 1u) ? UNI((unsigned)pw) : 0u;
+                    if (have >= need) break;
+                    const unsigned long long now = __builtin_amdgcn_s_memtime();
+                    if (have != seen) { seen = have; t_seen = now; }
+                    else if (now - t_seen > 16384ull) break;                         // (about ten DP rows' worth of time)
+                    if (UNI(GLD(abortf))) { dead = true; break; }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+#ifdef PWR_STAMPS
+                s3_pace += __builtin_amdgcn_s_memtime() - s3_p0;
+#endif
+                V3_LOAD_GROUP(g, cP, cM)
+                V3_LOAD_GROUP(g + 1, nP, nM)
+            }
+#ifdef PWR_STAMPS
+            s3_w = __builtin_amdgcn_s_memtime() - s3_b0; s3_fast += s3_b0 - s3_f0; s3_rows += x - x_in;
+#endif
+            if (x != x_in) {
+                if ((x & 15) == 0) {                                                 // the 16-row group is complete
+                    uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;
+#pragma unroll
+                    for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; }
+                    gacc = x >> 4; nacc = 0;
+                    if (lane == 0) GST(gprog + wave, x, 0);                          // progress, for the right neighbour's pacing
+                } else {
+                    nacc = x & 15;
+                }
+                a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+                sx = __builtin_amdgcn_readlane(scur, x & 63);
+                continue;                                                            // more ordinary rows, most likely
+            }
+            if (bail) continue;                                                      // (after the wait) try the row again
+        }
+        if (dead) break;
+
+        // ---- general path: one row, or one change of macro-strip
+#ifdef PWR_STAMPS
+        s3_t = __builtin_amdgcn_s_memtime();
+#endif
+        x = UNI(x); ms = UNI(ms); msn = UNI(msn); a = UNI(a); a_prev = UNI(a_prev); Bx_prev = UNI(Bx_prev);
+        sx = UNI(sx); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); gleft = UNI(gleft); gleftn = UNI(gleftn); ran_prev = UNI(ran_prev); cs = UNI(cs);
+        const int Bx = min(B, W - a);
+        const int ms_lo = (a - lo) / MS, ms_hi = (a + Bx - 1 - lo) / MS;
+        if (ms < ms_lo) {
+            // the macro-strip dropped out of the band for good: take over the one NW further right
+            ms += NW;
+            if (ms == msn) {
+#pragma unroll
+                for (int i = 0; i < C; ++i) { ug[i] = nu[i]; gg[i] = ng[i]; ig[i] = ni[i]; }
+                gleft = gleftn;
+                cs ^= 1;
+            } else {
+                while (ms < ms_lo) ms += NW;
+                V3_LOADS(ms, cs, ug, gg, ig, gleft)
+            }
+            msn = ms + NW;
+            V3_LOADS(msn, cs ^ 1, nu, ng, ni, gleftn)
+            ran_prev = 0;
+            continue;
+        }
+        if (ms > ms_hi) {                                   // no work for this wave in row x
+            ran_prev = 0;
+            V3_NEXT_ROW()
+            continue;
+        }
+        const int y0 = lo + ms * MS;
+        const int yq = y0 - 1;
+        const bool needP = ms > ms_lo;
+        const bool needM = x > 0 && yq >= a_prev && yq < a_prev + Bx_prev;
+        const bool needT = x > 0 && ((yq >= a_prev + Bx_prev) || !ran_prev);
+        unsigned ePx = 0, ePy = 0, eMy = 0, eTx = 0;
+        {
+            const unsigned tagx = tagbase | (unsigned)(x + 1), tagp = tagbase | (unsigned)x;
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (true) {
+                const unsigned long long eP = needP ? GLD(gleftw + 2 * (size_t)x) : 0ull;
+                const unsigned long long eQ = needP ? GLD(gleftw + 2 * (size_t)x + 1) : 0ull;
+                const unsigned long long eM = needM ? GLD(gleftw + 2 * (size_t)(x - 1) + 1) : 0ull;
+                const unsigned long long eT = needT ? GLD(gpt + (x - 1)) : 0ull;
+                ePx = UNI((unsigned)eP); ePy = UNI((unsigned)eQ); eMy = UNI((unsigned)eM); eTx = UNI((unsigned)eT);
+                const bool ready = (!needP || (UNI(TAGOF(eP)) == tagx && UNI(TAGOF(eQ)) == tagx)) &&
+                                   (!needM || UNI(TAGOF(eM)) == tagp) && (!needT || UNI(TAGOF(eT)) == tagp);
+                if (ready) break;
+                if (UNI(GLD(abortf)) || __builtin_amdgcn_s_memtime() - t0 > V3_TIMEOUT) { dead = true; V3_SAY(4) break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            if (dead) break;
+#ifdef PWR_STAMPS
+            s3_genwait += __builtin_amdgcn_s_memtime() - t0;
+#endif
+        }
+        int Mleft = (int)PWR_INF;
+        if (x == 0) Mleft = 0;
+        else if (yq < a_prev) Mleft = (int)PWR_INF;                              // PW:276
+        else if (needM) Mleft = (int)eMy;
+        else Mleft = gleft + (int)eTx;                                           // PW:285-295
+        const int P_in = needP ? (int)ePx : PWR_BIG;
+        if (x > 0 && !ran_prev) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) Mprev[i] = (unsigned)(gg[i] + (int)eTx);
+        }
+        if ((x >> 4) != gacc) { V3_FLUSH() gacc = x >> 4; }
+        V3_ALIGN_ACC(x & 15)
+        const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+        const int sxc = min(max(sx, 0), 3);                                      // PW:1503 Score(y, Seq_Bases[x])
+        const int rel0 = y0 + lc - a;
+        int tg[C];
+        int run = PWR_BIG;
+#pragma unroll
+        for (int i = 0; i < C; ++i) {
+            const int pm1 = i ? (int)Mprev[i > 0 ? i - 1 : 0] : pm1_0;
+            const int d = pm1 + ldsS1[cs][sxc][lc + i];
+            const int u = (int)Mprev[i] + ug[i];
+            accC[i] = (accC[i] << 1) | ((d <= u) ? 1u : 0u);
+            const int t3 = min(min(d, u), ig[i]);
+            tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bx) ? t3 : PWR_BIG;
+            run = min(run, tg[i]);
+        }
+        const int incl = wave_incl_min(run);
+        const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
+        const int P_end = min(P_in, __builtin_amdgcn_readlane(incl, 63));
+        int p = min(P_in, excl);
+        if (x != L - 1) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                accA[i] = (accA[i] << 1) | ((tg[i] >= p) ? 1u : 0u);
+                p = min(p, tg[i]);
+                Mprev[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
+            }
+        } else {
+            // last row: PW:1386 "M == M(x,y-1)" also moves left; keep the row for the entry scan
+            unsigned Mn[C];
+            unsigned fa = 0;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                fa |= (tg[i] >= p) ? (1u << i) : 0u;
+                p = min(p, tg[i]);
+                Mn[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
+            }
+            const unsigned mrow = needP ? ePy : PWR_INF;
+            const unsigned left0 = (unsigned)__builtin_amdgcn_update_dpp((int)mrow, (int)Mn[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                const unsigned lf = i ? Mn[i > 0 ? i - 1 : 0] : left0;
+                const bool inb = (unsigned)(rel0 + i) < (unsigned)Bx;
+                accA[i] = (accA[i] << 1) | ((((fa >> i) & 1u) || (inb && Mn[i] == lf)) ? 1u : 0u);
+                lastM[wave * MS + lc + i] = inb ? Mn[i] : 0xffffffffu;
+                Mprev[i] = Mn[i];
+            }
+        }
+        nacc = (x & 15) + 1;
+        if (lane == 63) {
+            GST(gmy + 2 * (size_t)x, P_end, x);
+            GST(gmy + 2 * (size_t)x + 1, Mprev[C - 1], x);
+            if (ms == ms_hi) GST(gpt + x, P_end, x);
+        }
+        ran_prev = 1;
+        V3_NEXT_ROW()
+#ifdef PWR_STAMPS
+        s3_gen += __builtin_amdgcn_s_memtime() - s3_t;
+#endif
+    }
+    V3_FLUSH()
+#ifdef PWR_STAMPS
+    if (lane == 0) printf("v3 wave%d L %d total %llu fast %llu (rows %llu entries %llu) bails %llu bailwait %llu pace %llu general %llu (waiting %llu)\n", wave, L, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_clk0), s3_fast, s3_rows, s3_entries, s3_bails, s3_bailwait, s3_pace, s3_gen, s3_genwait);
+#endif
+    if (lane == 0 && !dead) GST(gprog + wave, L, 0);
+    if (dead) {
+        if (lane == 0) { __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+        return;
+    }
+    if (wave == 0 && lane == 0) {
+        m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
+        m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
+        m->rounds = 0;
+        atomicAdd(&st.hdr->cells_computed, m->cells);
+    }
+#undef GLD
+#undef GST
+#undef TAGOF
+#undef V3_LOADS
+#undef V3_LOAD_GROUP
+#undef V3_ALIGN_ACC
+#undef V3_FLUSH
+#undef V3_ROTATE_BLOCK
+#undef V3_NEXT_ROW
+}
+
+// ---------------------------------------------------------------------------------------------
 // trace for the wave-pipeline layout (dirs indexed by (y - lo) mod RS, the same word for a column
 // in every row of a 16-row group).  Also picks the entry column (PW:1352-1360) from lastM.
 // ---------------------------------------------------------------------------------------------
@@ -2085,6 +2600,7 @@ struct pwr_ctx {
     int par_trace = 1;                    // 1: speculative-parallel traceback (k_trace_par), 0: single-wave k_trace_wp
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int fill_mode = 3;
+    unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
     int wp_waves = 5;                     // waves per DP of the v2 wave pipeline: 9/8/5/4/3 with 2/3/4/6/8 columns per lane                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 3: wave pipeline in lock-step rounds (k_fill_v2)
     int cells_per_thread = 1;
     // stats
@@ -2226,7 +2742,7 @@ static void host_trim(pwr_ctx *c)
 static int alloc_jobs(pwr_ctx *c, int njobs)
 {
     JobBufs &jb = c->jb;
-    if (c->B > 1000 || c->fill_mode != 3) c->wp_waves = 9;
+    if (c->B > 1000 || (c->fill_mode != 3 && c->fill_mode != 4)) c->wp_waves = 9;
     const int wpC = c->wp_waves == 8 ? 3 : c->wp_waves == 5 ? 4 : c->wp_waves == 4 ? 6 : c->wp_waves == 3 ? 8 : (c->B <= 1024 ? 2 : 4);
     const int NC = c->fill_mode ? c->wp_waves * 64 * wpC : c->threads * c->cells_per_thread;
     jb.layout = c->fill_mode ? 1 : 0;
@@ -2246,9 +2762,18 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     if ((rc = dmalloc(c, &jb.aux, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.gbase, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.desc, (size_t)njobs * jb.Lmax))) return rc;
-    jb.wpNW = c->fill_mode == 3 ? c->wp_waves : 0;
+    jb.wpNW = (c->fill_mode == 3 || c->fill_mode == 4) ? c->wp_waves : 0;
     jb.wpMS = 64 * wpC;
     if ((rc = dmalloc(c, &jb.lastM, (size_t)njobs * jb.NC))) return rc;
+    if (c->fill_mode == 4) {
+        const size_t nmb = (size_t)njobs * c->wp_waves * jb.Lmax * 2, npt = (size_t)njobs * jb.Lmax;
+        if ((rc = dmalloc(c, &jb.gmb, nmb))) return rc;
+        if ((rc = dmalloc(c, &jb.gpt, npt))) return rc;
+        if ((rc = dmalloc(c, &jb.gprog, (size_t)njobs * 16))) return rc;
+        if (hipMemset(jb.gmb, 0, nmb * 8) != hipSuccess || hipMemset(jb.gpt, 0, npt * 8) != hipSuccess ||
+            hipMemset(jb.gprog, 0, (size_t)njobs * 16 * 8) != hipSuccess) return PWR_ERR_DEVICE;
+        c->fill_epoch = 0;
+    }
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
     if (hipMemset(jb.meta, 0, sizeof(JobMeta) * njobs) != hipSuccess) return PWR_ERR_DEVICE;
     c->njobs = njobs;
@@ -2259,7 +2784,7 @@ static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
     dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.rec); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
-    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, c->d_jobrows);
+    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gpt); dfree(c, jb.gprog); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -2439,7 +2964,26 @@ static int launch_fill(pwr_ctx *c, int njobs)
         c->ev_used++;
         HIPC(hipEventRecord(e0, c->stream));
     }
-    if (c->fill_mode == 3) {
+    if (c->fill_mode == 4) {
+        // one 64-thread work-group per wave; grid.x = 8 keeps the waves of a DP on one XCD (work-groups go to the
+        // XCDs round-robin by linear id)
+        if (++c->fill_epoch >= (1u << 15)) {
+            const size_t nmb = (size_t)c->njobs * c->wp_waves * c->jb.Lmax * 2, npt = (size_t)c->njobs * c->jb.Lmax;
+            HIPC(hipMemsetAsync(c->jb.gmb, 0, nmb * 8, c->stream));
+            HIPC(hipMemsetAsync(c->jb.gpt, 0, npt * 8, c->stream));
+            HIPC(hipMemsetAsync(c->jb.gprog, 0, (size_t)c->njobs * 16 * 8, c->stream));
+            c->fill_epoch = 1;
+        }
+        c->jb.tagbase = c->fill_epoch << 17;
+        c->jb.njobs_launched = njobs;
+        const dim3 grid(8, c->wp_waves, (njobs + 7) / 8);
+        if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4>), grid, dim3(64), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3>), grid, dim3(64), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6>), grid, dim3(64), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8>), grid, dim3(64), 0, c->stream, c->st, c->jb);
+        else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v3<9, 2>), grid, dim3(64), 0, c->stream, c->st, c->jb);
+        else hipLaunchKernelGGL((k_fill_v3<9, 4>), grid, dim3(64), 0, c->stream, c->st, c->jb);
+    } else if (c->fill_mode == 3) {
         if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v2<5, 4>), dim3(njobs), dim3(5 * 64), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v2<8, 3>), dim3(njobs), dim3(8 * 64), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v2<4, 6>), dim3(njobs), dim3(4 * 64), 0, c->stream, c->st, c->jb);
@@ -2690,7 +3234,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!c || !key) return PWR_ERR_ARG;
     if (!strcmp(key, "window")) { if (value < 1 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
-    if (!strcmp(key, "fill")) { if (c->on_device || (value != 0 && value != 1 && value != 3)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
+    if (!strcmp(key, "fill")) { if (c->on_device || (value != 0 && value != 1 && value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "ptrace")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
     if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }

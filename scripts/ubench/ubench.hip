@@ -11,7 +11,9 @@ __global__ void kb(unsigned long long *out, int *sink, int mode) {
     int lane = threadIdx.x & 63;
     lds[threadIdx.x & 255] = lane;
     __syncthreads();
-    int v = lane, w = lane * 3, s = mode;
+    int v = lane, w = lane * 3, s = mode, w2 = lane + 7;
+    int *sinkp = sink + threadIdx.x;
+    asm volatile("s_mov_b64 s[22:23], exec" ::: "s22", "s23");
     unsigned long long t0 = __builtin_readcyclecounter();
     if (mode == 0) {          // dependent VALU chain, 32 per iter
         for (int i = 0; i < N; ++i) { REP32(asm volatile("v_add_u32 %0, %0, %1" : "+v"(v) : "v"(w));) }
@@ -56,18 +58,33 @@ __global__ void kb(unsigned long long *out, int *sink, int mode) {
     } else if (mode == 17) {  // salu->valu: s_add; v_add using sgpr
         for (int i = 0; i < N; ++i) { REP32(asm volatile("s_add_u32 %1, %1, 1\n v_add_u32 %0, %0, %1" : "+v"(v), "+s"(s) :: "scc");) }
     }
+    else if (mode == 18) {  // v_cmp e64 -> sgpr pair -> v_addc carry-in from sgpr pair
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_cmp_le_i32_e64 s[20:21], %0, %1\n v_addc_co_u32_e64 %0, s[20:21], %0, %0, s[20:21]" : "+v"(v) : "v"(w) : "s20", "s21");) }
+    } else if (mode == 19) {  // v_cmp -> vcc -> v_addc carry-in from vcc
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_cmp_le_i32_e32 vcc, %0, %1\n v_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(v) : "v"(w) : "vcc");) }
+    } else if (mode == 20) {  // v_readlane -> VALU reads that sgpr
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_readlane_b32 s20, %0, 5\n v_add_u32 %0, %0, s20" : "+v"(v) :: "s20");) }
+    } else if (mode == 21) {  // v_cmp e64 sgpr pair -> v_cndmask with that pair
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_cmp_le_i32_e64 s[20:21], %0, %1\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(v) : "v"(w) : "s20", "s21");) }
+    } else if (mode == 22) {  // global store (lane-masked) issue cost
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("global_store_dword %0, %1, off" :: "v"(sinkp), "v"(v) : "memory");) }
+    } else if (mode == 23) {  // s_and_saveexec + restore
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("s_and_saveexec_b64 s[20:21], s[22:23]\n v_add_u32 %0, %0, 1\n s_or_b64 exec, exec, s[20:21]" : "+v"(v) :: "s20", "s21");) }
+    } else if (mode == 24) {  // independent v_cmp e64 + addc pairs on 2 chains
+        for (int i = 0; i < N; ++i) { REP32(asm volatile("v_cmp_le_i32_e64 s[20:21], %0, %2\n v_cmp_le_i32_e64 s[24:25], %1, %2\n v_addc_co_u32_e64 %0, s[20:21], %0, %0, s[20:21]\n v_addc_co_u32_e64 %1, s[24:25], %1, %1, s[24:25]" : "+v"(v), "+v"(w2) : "v"(w) : "s20", "s21", "s24", "s25");) }
+    }
     unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
-    sink[threadIdx.x] = v + w + s;
+    sink[threadIdx.x] = v + w + s + w2;
 }
 
 int main() {
     unsigned long long *d; int *sink; hipMalloc(&d, 64); hipMalloc(&sink, 4096);
     const char *names[] = {"dep v_add", "2 indep v_add (pair)", "readfirstlane+s_add+v_mov (3)", "dep s_add", "s_branch taken(+skip nop)",
         "s_nop1 + dpp min", "ds_read chase (+waitcnt+shl)", "v_cmp+v_cndmask (2)", "v_cmp+saveexec+v_add+restore (4)", "ds_write+ds_read+wait (3)",
-        "readlane+s_cmp+cbranch nt+v_add (4)", "s_cmp+cbranch taken (2)", "dep v_min3", "s_memtime+wait", "s_barrier", "ds_write+wait", "indep readfirstlane", "s_add + v_add sgpr (2)"};
-    for (int threads = 64; threads <= 320; threads += 256)
-    for (int m = 0; m < 18; ++m) {
+        "readlane+s_cmp+cbranch nt+v_add (4)", "s_cmp+cbranch taken (2)", "dep v_min3", "s_memtime+wait", "s_barrier", "ds_write+wait", "indep readfirstlane", "s_add + v_add sgpr (2)", "v_cmp_e64 sgpr + v_addc sgpr (2)", "v_cmp vcc + v_addc vcc (2)", "v_readlane + v_add sgpr (2)", "v_cmp_e64 sgpr + v_cndmask sgpr (2)", "global_store_dword", "saveexec + v_add + restore (3)", "2x(v_cmp_e64) + 2x(v_addc) indep (4)"};
+    for (int threads = 64; threads <= 64; threads += 256)
+    for (int m = 0; m < 25; ++m) {
         hipLaunchKernelGGL(kb, dim3(1), dim3(threads), 0, 0, d, sink, m);
         hipDeviceSynchronize();
         hipLaunchKernelGGL(kb, dim3(1), dim3(threads), 0, 0, d, sink, m);

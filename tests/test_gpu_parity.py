@@ -68,20 +68,21 @@ def _row_by_row(name, bw, rounds, oracle, **opts):
     g.close()
 
 
-@pytest.mark.parametrize("fill", [3, 1, 0], ids=["v2", "wavepipe", "ldsfill"])
+@pytest.mark.parametrize("fill", [4, 3, 1, 0], ids=["v3", "v2", "wavepipe", "ldsfill"])
 @pytest.mark.parametrize("name,bw,rounds", STEP_CASES, ids=[c[0] for c in STEP_CASES])
 def test_row_by_row_against_oracle(name, bw, rounds, fill, oracle):
     _row_by_row(name, bw, rounds, oracle, fill=fill)
 
 
-@pytest.mark.parametrize("waves", [3, 4, 8, 9])
+@pytest.mark.parametrize("fill", [4, 3], ids=["v3", "v2"])
+@pytest.mark.parametrize("waves", [3, 4, 5, 8, 9])
 @pytest.mark.parametrize("name,bw,rounds", [STEP_CASES[0], STEP_CASES[4], STEP_CASES[6]], ids=["toy_a_b1000", "lowcov_b300", "deep_b200"])
-def test_wave_geometries_row_by_row(name, bw, rounds, waves, oracle):
-    """The other macro-strip widths of the default fill kernel (3/4/8/9 waves per DP)."""
-    _row_by_row(name, bw, rounds, oracle, fill=3, waves=waves)
+def test_wave_geometries_row_by_row(name, bw, rounds, waves, fill, oracle):
+    """All macro-strip widths (3/4/5/8/9 waves per DP) of the two wave-pipeline fill kernels."""
+    _row_by_row(name, bw, rounds, oracle, fill=fill, waves=waves)
 
 
-@pytest.mark.parametrize("fill", [3, 1, 0], ids=["v2", "wavepipe", "ldsfill"])
+@pytest.mark.parametrize("fill", [4, 3, 1, 0], ids=["v3", "v2", "wavepipe", "ldsfill"])
 @pytest.mark.parametrize("window", [1, 3, 64])
 def test_batched_rounds_match_sequential_oracle(window, fill, oracle):
     """Speculative batches of any size must give the row-sequential result (commit in row order,
@@ -229,7 +230,7 @@ def test_medium_properties_and_kernel_cross_check():
     from repeatresolver_amd.realigner import PWReAligner
     rows = [bytes(r) for r in dg.make_msa("tree_medium")]
     ref = None
-    for fill, window, waves in ((3, 8, 5), (3, 1, 5), (1, 4, 9), (3, 8, 9), (3, 8, 4)):
+    for fill, window, waves in ((4, 8, 9), (3, 8, 5), (4, 1, 5), (1, 4, 9), (3, 8, 9), (3, 8, 4)):
         g = PWReAligner(rows, bandwidth=1000, fill=fill, window=window, waves=waves)
         g.trim_ends()
         before = [r.replace(b"-", b"").replace(b" ", b"") for r in g.export_rows()]
