@@ -94,7 +94,6 @@ struct JobBufs {
     unsigned *lastM;               // [njobs][NC]     scores of the last DP row (wave-pipeline fill)
     unsigned long long *gmb;       // [njobs][NW][Lmax][2] k_fill_v3: {P_end, tag}, {M_last, tag} per wave and DP row
     unsigned long long *gpt;       // [njobs][Lmax]   k_fill_v3: {Ptot, tag} per DP row
-    unsigned long long *gprog;     // [njobs][NW]     k_fill_v3: {rows a wave is done with, tag of row 0}
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
     int njobs_launched;
     int layout;                    // 0: dirs indexed by band cell (y - anf(x)); 1: by (y - lo) mod NC
@@ -1234,6 +1233,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                     nacc = x & 15;
                     a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
                     sx = __builtin_amdgcn_readlane(scur, x & 63);
+                    if (!not_ready && budget > 0) continue;                          // more ordinary rows, most likely
                 }
             }
             if (not_ready || budget <= 0) break;
@@ -1400,63 +1400,87 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 
 // ---------------------------------------------------------------------------------------------
 // fill v3: the same wave pipeline as k_fill_v2, spread over compute units.  Every wave of a DP is its own
-// 64-thread work-group, so each gets a SIMD to itself (in k_fill_v2 the fifth wave of a work-group shares one,
-// and that pair sets the pace); the grid is (8, NW, jobs / 8) so that the NW waves of one DP land on the same
-// XCD and talk through its L2.  What a wave publishes per DP row goes to global memory:
+// work-group, so each gets a SIMD to itself (in k_fill_v2 the fifth wave of a work-group shares one with the
+// first, and that pair sets the pace); the grid is (8, NW, jobs / 8) so that the NW work-groups of one DP land
+// on the same XCD and talk through its L2.  What a wave publishes per DP row goes to global memory:
 //   gmb[(w * Lmax + x) * 2 + 0]  {P_end, tag}   the running minimum its right neighbour continues
 //   gmb[(w * Lmax + x) * 2 + 1]  {M_last, tag}  the score of its last column
 //   gpt[x]                       {Ptot, tag}    the minimum of the whole row (posted by the wave that ends the band)
 // each one aligned 64-bit word, stored and loaded whole (relaxed agent-scope atomics) and self-validating:
-// tag = launch epoch << 17 | row + 1, so nothing has to be cleared between launches.  There are no rounds and no
-// barriers: a wave simply runs down its rows.  It reads its left neighbour's words sixteen rows at a time (lane
-// l of a register pair holds row 16 g + l, fetched while group g - 1 is computed, consumed with v_readlane), so
-// in the steady state it trails the neighbour by a group or two and never waits; when a word is not there yet it
-// takes the row back, re-reads the group until it is (bounded: a time-out flags the job) and goes on.
-// Dependencies only point to the left neighbour, whose own never point back, so this cannot deadlock as long as
-// all NW work-groups are resident -- NW <= 9 waves per DP and at most a few dozen DPs per launch on 256 CUs.
+// tag = launch epoch << 17 | row + 1, so nothing has to be cleared between launches.  There are no rounds and
+// no barriers: a wave simply runs down its rows and waits (bounded by a time-out that flags the job) where a
+// word is missing.  Dependencies only point to the left neighbour, whose own never point back, so this cannot
+// deadlock as long as all NW work-groups are resident -- NW <= 9 per DP, a few dozen DPs per launch, 256 CUs.
+//
+// Every work-group has a second wave, the FETCHER.  It sits on another SIMD of the same CU, polls the left
+// neighbour's published words of the rows [wx - 1, wx + 63) -- wx = the worker's progress -- and copies every
+// valid one into an LDS ring; the worker reads the ring exactly as k_fill_v2 reads its mailboxes (one LDS
+// access, waiting in the middle of the row if the word is not there yet).  The worker therefore trails its
+// neighbour by one poll of the fetcher (a few DP rows), and the L2 round trip is never on its critical path.
+// Ring words keep their row tags, so an old occupant of a slot is never mistaken for the row in demand.
 // ---------------------------------------------------------------------------------------------
-#ifdef PWR_STAMPS
-#define V3_SAY(N) if (lane == 0) printf("v3 timeout #%d: job %d wave %d x %d L %d\n", N, job, wave, x, L);
-#else
-#define V3_SAY(N)
-#endif
-#define V3_G 16                                      // rows per mailbox register group (= rows per traceback word)
 #define V3_TIMEOUT (1ull << 31)                      // shader clocks (about a second) a wave waits for its neighbour
+#define V4_RB 128                                    // ring slots (rows); the fetcher looks at most 64 rows ahead
 
 template <int NW, int C>
-__global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
+__global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 {
-#ifdef PWR_STAMPS
-    unsigned long long s3_fast = 0, s3_bailwait = 0, s3_pace = 0, s3_gen = 0, s3_genwait = 0, s3_rows = 0, s3_bails = 0, s3_entries = 0, s3_t = 0, s3_mlast = 0;
-#endif
     constexpr int MS = 64 * C, RS = NW * MS;
     __shared__ __attribute__((aligned(16))) int ldsS1[2][4][MS];
-    const int job = blockIdx.x + 8 * blockIdx.z, lane = threadIdx.x;
+    __shared__ unsigned long long rP[V4_RB], rM[V4_RB], rT[V4_RB];      // the neighbour's {P_end, tag}, {M_last, tag}; {Ptot, tag}
+    __shared__ int wprog, wdone;                                         // worker's progress (rows), worker finished
+    const int job = blockIdx.x + 8 * blockIdx.z, lane = threadIdx.x & 63;
+    const int role = UNI((int)threadIdx.x >> 6);                          // 0 worker, 1 fetcher
     const int wave = blockIdx.y;
     if (job >= jb.njobs_launched) return;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
     if (L <= 0 || !m->ok) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x < V4_RB) { rP[threadIdx.x] = 0; rM[threadIdx.x] = 0; rT[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) { wprog = 0; wdone = 0; }
+    __syncthreads();
 
+    const int wl = (wave + NW - 1) % NW;
+    const unsigned tagbase = jb.tagbase;
+    unsigned long long *const gmy = jb.gmb + ((size_t)job * NW + wave) * (size_t)jb.Lmax * 2;
+    const unsigned long long *const gleftw = jb.gmb + ((size_t)job * NW + wl) * (size_t)jb.Lmax * 2;
+    unsigned long long *const gpt = jb.gpt + (size_t)job * jb.Lmax;
+    int *const abortf = &m->abort;
+#define GLD(PTR) __hip_atomic_load((PTR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GST(PTR, VAL, ROW) __hip_atomic_store((PTR), ((unsigned long long)(tagbase | (unsigned)((ROW) + 1)) << 32) | (unsigned)(VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define TAGOF(W64) ((unsigned)((W64) >> 32))
+#define LLD(REF) __hip_atomic_load(&(REF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define LST(REF, V) __hip_atomic_store(&(REF), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+    if (role == 1) {
+        // ---- fetcher
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (true) {
+            if (UNI(LLD(wdone))) break;
+            const int wx = UNI(LLD(wprog));
+            const int r = wx - 1 + lane;                                          // row wx needs words of row wx - 1 too
+            if (r >= 0 && r < L) {
+                const unsigned long long p = GLD(gleftw + 2 * (size_t)r), q = GLD(gleftw + 2 * (size_t)r + 1), t = GLD(gpt + r);
+                const unsigned tagr = tagbase | (unsigned)(r + 1);
+                if (TAGOF(p) == tagr && TAGOF(q) == tagr) { LST(rP[r & (V4_RB - 1)], p); LST(rM[r & (V4_RB - 1)], q); }   // P before M
+                if (TAGOF(t) == tagr) LST(rT[r & (V4_RB - 1)], t);
+            }
+            if (UNI(GLD(abortf)) || __builtin_amdgcn_s_memtime() - t0 > 16 * V3_TIMEOUT) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return;
+    }
+
+    // ---- worker
     const int lo = UNI(m->lo), hi = UNI(m->hi), W = UNI(m->W), B = st.B, H = st.H;
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint8_t *seq = st.seq + st.rowoff[UNI(m->k)];
     const int4 *rec2 = jb.rec2 + (size_t)job * jb.colcap * 2;
     uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
     unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
-    const int wl = (wave + NW - 1) % NW;
     const int lc = lane * C;
-    const unsigned tagbase = jb.tagbase;
-    unsigned long long *const gmy = jb.gmb + ((size_t)job * NW + wave) * (size_t)jb.Lmax * 2;      // this wave's words
-    const unsigned long long *const gleftw = jb.gmb + ((size_t)job * NW + wl) * (size_t)jb.Lmax * 2;   // the left neighbour's
-    unsigned long long *const gpt = jb.gpt + (size_t)job * jb.Lmax;
-    unsigned long long *const gprog = jb.gprog + (size_t)job * 16;
-    int *const abortf = &m->abort;
-#define GLD(PTR) __hip_atomic_load((PTR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define GST(PTR, VAL, ROW) __hip_atomic_store((PTR), ((unsigned long long)(tagbase | (unsigned)((ROW) + 1)) << 32) | (unsigned)(VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define TAGOF(W64) ((unsigned)((W64) >> 32))
-#define V3_LOADS(MSX, SLOT, AU, AG, AI, GL)                                                      \
+#define V4_LOADS(MSX, SLOT, AU, AG, AI, GL)                                                      \
     {                                                                                            \
         _Pragma("unroll") for (int i = 0; i < C; ++i) {                                          \
             const int y_ = lo + (MSX) * MS + lc + i;                                             \
@@ -1476,8 +1500,8 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
     int gleft = 0, gleftn = 0;
     int ms = wave, msn = wave + NW;
     int cs = 0;
-    V3_LOADS(ms, 0, ug, gg, ig, gleft)
-    V3_LOADS(msn, 1, nu, ng, ni, gleftn)
+    V4_LOADS(ms, 0, ug, gg, ig, gleft)
+    V4_LOADS(msn, 1, nu, ng, ni, gleftn)
 
     unsigned Mprev[C], accA[C], accC[C];
 #pragma unroll
@@ -1496,29 +1520,20 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
     int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H), a_prev = 0, Bx_prev = 0;
     int sx = __builtin_amdgcn_readlane(scur, 0);
 
-    // the left neighbour's words of row group cg (lane l: row V3_G * cg + l; lanes 16.. repeat) and of group cg + 1
-    unsigned long long cP = 0, cM = 0, nP = 0, nM = 0;
-    int cg = -2;
-    unsigned pm15 = 0, pm15t = 0;                          // {M_last, tag} of the last row of group cg - 1
-#define V3_LOAD_GROUP(G_, QP, QM)                                                                \
-    {                                                                                            \
-        const int r_ = min((G_) * V3_G + (lane & (V3_G - 1)), L - 1);                            \
-        QP = GLD(gleftw + 2 * (size_t)r_); QM = GLD(gleftw + 2 * (size_t)r_ + 1);               \
-    }
-#define V3_ALIGN_ACC(WANT)                                                                       \
+#define V4_ALIGN_ACC(WANT)                                                                       \
     if (nacc != (WANT)) {                                                                        \
         const int sh_ = (WANT) - nacc;                                                           \
         _Pragma("unroll") for (int i = 0; i < C; ++i) { accA[i] <<= sh_; accC[i] <<= sh_; }      \
         nacc = (WANT);                                                                           \
     }
-#define V3_FLUSH()                                                                               \
+#define V4_FLUSH()                                                                               \
     if (gacc >= 0) {                                                                             \
-        V3_ALIGN_ACC(16)                                                                         \
+        V4_ALIGN_ACC(16)                                                                         \
         uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;                \
         _Pragma("unroll") for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; } \
         gacc = -1; nacc = 0;                                                                     \
     }
-#define V3_ROTATE_BLOCK()                                                                        \
+#define V4_ROTATE_BLOCK()                                                                        \
     {                                                                                            \
         blk = x >> 6;                                                                            \
         wcur = wnxt; scur = snxt; dca = dna; dcb = dnb; dcf = (wave < 8 ? dnz : dnw) >> fsh;     \
@@ -1527,13 +1542,13 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
         const uint4 e4_ = desc[min(x + 64 + lane, L - 1)];                                       \
         dna = e4_.x; dnb = e4_.y; dnz = e4_.z; dnw = e4_.w;                                      \
     }
-#define V3_NEXT_ROW()                                                                            \
+#define V4_NEXT_ROW()                                                                            \
     {                                                                                            \
         a_prev = a; Bx_prev = Bx;                                                                \
         ++x;                                                                                     \
-        if (lane == 0) GST(gprog + wave, x, 0);                                                  \
+        if (lane == 0) LST(wprog, x);                                                            \
         if (x < L) {                                                                             \
-            if ((x >> 6) != blk) V3_ROTATE_BLOCK()                                               \
+            if ((x >> 6) != blk) V4_ROTATE_BLOCK()                                               \
             a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);                             \
             sx = __builtin_amdgcn_readlane(scur, x & 63);                                        \
         }                                                                                        \
@@ -1541,77 +1556,32 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
 
     bool dead = false;
     while (x < L && !dead) {
-        ran_prev = UNI(ran_prev); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); ms = UNI(ms); cs = UNI(cs); gleft = UNI(gleft); cg = UNI(cg);
+        ran_prev = UNI(ran_prev); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); ms = UNI(ms); cs = UNI(cs); gleft = UNI(gleft);
         x = UNI(x);
-        // ---- fast path: runs of ordinary rows (flagged by the gather), at most one 16-row group per trip
+        // ---- fast path: runs of ordinary rows (flagged by the gather), as in k_fill_v2
         if (ran_prev && x < L - 1) {
-#ifdef PWR_STAMPS
-            ++s3_entries; const unsigned long long s3_f0 = __builtin_amdgcn_s_memtime(); unsigned long long s3_w = 0;
-#endif
-            if ((x >> 4) != gacc) { V3_FLUSH() gacc = x >> 4; }
-            const int g = x >> 4;
-            if (cg != g) {                                                       // bring the mailbox registers to group g
-                if (cg + 1 == g) {
-                    pm15 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cM, V3_G - 1);
-                    pm15t = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cM), V3_G - 1);
-                    cP = nP; cM = nM;
-                } else {
-                    pm15t = 0;
-                    V3_LOAD_GROUP(g, cP, cM)
-                }
-                cg = g;
-                V3_LOAD_GROUP(g + 1, nP, nM)
-            }
+            if ((x >> 4) != gacc) { V4_FLUSH() gacc = x >> 4; }
+            unsigned mlast_v = (unsigned)LLD(rM[(x - 1) & (V4_RB - 1)]);          // M_last(x-1) of the left neighbour
             const int y0f = lo + ms * MS;
             const int rel00 = y0f + lc;
-            // rows this trip may take: to the end of the 16-row group, not the last row of a 64-row block (that one
-            // follows below, it needs the next block's registers), not the last row
-            const int xstop = UNI(min(min(L - 1, ((blk + 1) << 6) - 1), (g + 1) << 4));
+            const int xstop = UNI(min(L - 1, ((blk + 1) << 6) - 1));
             const int x_in = x;
-            V3_ALIGN_ACC(x & 15)
+            V4_ALIGN_ACC(x & 15)
             unsigned db = (unsigned)__builtin_amdgcn_readlane((int)dcb, x & 63);
             int sgr[C];
 #pragma unroll
             for (int i = 0; i < C; ++i) sgr[i] = ldsS1[cs][min(db >> 16, 3u)][lc + i];
-            // M_last(x-1) of the left neighbour, if row x wants it: it was posted together with the P_end this wave
-            // consumed in row x-1, so it is in the group registers (or, for the first row of a group, was saved from the
-            // previous group's); only after a detour through the general path may it have to come from memory
-            int mlast = (int)PWR_INF;
-            {
-                const int fl0 = __builtin_amdgcn_readlane((int)dcf, x & 63);
-                if ((fl0 & 5) == 5) {
-                    const unsigned want = tagbase | (unsigned)x;
-                    unsigned v_ = pm15, t_ = pm15t;
-                    if (x & (V3_G - 1)) {
-                        v_ = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cM, (x - 1) & (V3_G - 1));
-                        t_ = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cM), (x - 1) & (V3_G - 1));
-                    }
-                    if (t_ != want) {
-                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-                        while (true) {
-                            const unsigned long long w_ = GLD(gleftw + 2 * (size_t)(x - 1) + 1);
-                            v_ = UNI((unsigned)w_);
-                            if (UNI(TAGOF(w_)) == want) break;
-                            if (UNI(GLD(abortf)) || __builtin_amdgcn_s_memtime() - t0 > V3_TIMEOUT) { dead = true; V3_SAY(1) break; }
-                            __builtin_amdgcn_s_sleep(2);
-                        }
-                    }
-                    mlast = (int)v_;
-                }
-            }
 #pragma unroll
             for (int i = 0; i < C; ++i) asm volatile("" : "+v"(sgr[i]));
+            asm volatile("" : "+v"(mlast_v));
             int cnt = xstop - x - 1;
-            int bail = dead ? 1 : 0;
-            if (dead) cnt = -1;
-            // One ordinary row.  fl = its flags, dbn = the {Bx, base} descriptor word of the row after it.
             auto fast_row = [&](const int fl, const unsigned dbn) __attribute__((always_inline)) {
                 const int af = __builtin_amdgcn_readlane((int)dca, x & 63);
                 const int Bxf = (int)(db & 0xffffu);
                 a_prev = af; Bx_prev = Bxf;
                 db = dbn;
-                const int Mleft = (fl & 4) ? mlast : (int)PWR_INF;
-                const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+                const int Mleft_v = (fl & 4) ? (int)mlast_v : (int)PWR_INF;
+                const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft_v, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
                 const int rel0 = rel00 - af;
                 int tg[C];
                 int run = FBIG;
@@ -1625,145 +1595,103 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
                     tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bxf) ? t3 : FBIG;
                     run = min(run, tg[i]);
                 }
+                // the neighbour's words of this row, from the ring (M first: the fetcher stores it last)
+                unsigned long long fM = LLD(rM[x & (V4_RB - 1)]);
+                unsigned fP = __hip_atomic_load((unsigned *)&rP[x & (V4_RB - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __builtin_amdgcn_sched_barrier(0);
-                // The scan: six dependent DPP steps, each two issue slots behind the one before; the slots are filled by
-                // hand with the fetch of the next row's substitution column and the neighbour's words of this row.
-#define V3_SCAN_STEP(CTRL, RMASK) { const int t_ = __builtin_amdgcn_update_dpp(PWR_BIG, incl, CTRL, RMASK, 0xF, false); incl = min(incl, t_); }
-#define V3_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define V4_SCAN_STEP(CTRL, RMASK) { const int t_ = __builtin_amdgcn_update_dpp(PWR_BIG, incl, CTRL, RMASK, 0xF, false); incl = min(incl, t_); }
+#define V4_FENCE() __builtin_amdgcn_sched_barrier(0)
                 int incl = run;
-                V3_SCAN_STEP(DPP_ROW_SHR(1), 0xF) V3_FENCE();
+                V4_SCAN_STEP(DPP_ROW_SHR(1), 0xF) V4_FENCE();
                 const unsigned sxn = min(db >> 16, 3u);
+                V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(2), 0xF) V4_FENCE();
                 const int *const srow = &ldsS1[cs][sxn][lc];
-                V3_FENCE(); V3_SCAN_STEP(DPP_ROW_SHR(2), 0xF) V3_FENCE();
+                V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(4), 0xF) V4_FENCE();
 #pragma unroll
                 for (int i = 0; i < C; ++i) sgr[i] = srow[i];
-                const unsigned pval = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cP, x & (V3_G - 1));
-                V3_FENCE(); V3_SCAN_STEP(DPP_ROW_SHR(4), 0xF) V3_FENCE();
-                const unsigned ptag = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cP), x & (V3_G - 1));
-                const unsigned mval = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)cM, x & (V3_G - 1));
-                V3_FENCE(); V3_SCAN_STEP(DPP_ROW_SHR(8), 0xF) V3_FENCE();
-                const unsigned mtag = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cM), x & (V3_G - 1));
+                V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(8), 0xF) V4_FENCE();
                 const unsigned tagx = tagbase | (unsigned)(x + 1);
-                V3_FENCE(); V3_SCAN_STEP(DPP_ROW_BCAST15, 0xA) V3_FENCE();
-                const unsigned miss = (fl & 2) ? ((ptag ^ tagx) | (mtag ^ tagx)) : 0u;
-                V3_FENCE(); V3_SCAN_STEP(DPP_ROW_BCAST31, 0xC) V3_FENCE();
-#undef V3_SCAN_STEP
-#undef V3_FENCE
+                V4_FENCE(); V4_SCAN_STEP(DPP_ROW_BCAST15, 0xA) V4_FENCE();
+                unsigned long long *const gq = gmy + 2 * (size_t)x;
+                V4_FENCE(); V4_SCAN_STEP(DPP_ROW_BCAST31, 0xC) V4_FENCE();
+#undef V4_SCAN_STEP
+#undef V4_FENCE
                 const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
-                if (miss == 0u) {
-                    const int P_in = (fl & 2) ? (int)pval : PWR_BIG;
-                    const int P_end_v = min(P_in, incl);                             // lane 63: the row's running minimum so far
-                    int p = min(min(P_in, excl), FBIG);
+                if (fl & 2) {
+                    if (UNI(TAGOF(fM)) != tagx) {
+                        // not there yet: wait for the fetcher to deliver it (bounded by a time-out that flags the job)
+                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                        for (unsigned spin = 1;; ++spin) {
+                            fM = LLD(rM[x & (V4_RB - 1)]);
+                            fP = __hip_atomic_load((unsigned *)&rP[x & (V4_RB - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (UNI(TAGOF(fM)) == tagx) break;
+                            if ((spin & 1023u) == 0 && (__builtin_amdgcn_s_memtime() - t0 > V3_TIMEOUT || UNI(GLD(abortf)))) { dead = true; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    }
+                }
+                if (!dead) {
+                    const int P_in_v = (fl & 2) ? (int)fP : PWR_BIG;
+                    const int P_end_v = min(P_in_v, incl);
+                    int p = min(min(P_in_v, excl), FBIG);
 #pragma unroll
                     for (int i = 0; i < C; ++i) {
                         accA[i] = acc_push(accA[i], __builtin_amdgcn_sicmp(tg[i], p, ICMP_SGE));
                         p = min(p, tg[i]);
                         Mprev[i] = min((unsigned)(gg[i] + p), PWR_INF);
                     }
-                    mlast = (int)mval;                                               // valid whenever the next row needs it
+                    mlast_v = (unsigned)fM;
                     if (lane == 63) {
-                        GST(gmy + 2 * (size_t)x, P_end_v, x);
-                        GST(gmy + 2 * (size_t)x + 1, Mprev[C - 1], x);
-                        if (fl & 8) GST(gpt + x, P_end_v, x);                        // the band ends in this macro-strip
+                        GST(gq, P_end_v, x);
+                        GST(gq + 1, Mprev[C - 1], x);
+                        if (fl & 8) GST(gpt + x, P_end_v, x);
                     }
                     ++x; --cnt;
+                    if ((x & 15) == 0) {                                             // the 16-row group is complete
+                        uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;
+#pragma unroll
+                        for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; }
+                        gacc = x >> 4;
+                        if (lane == 0) LST(wprog, x);                                // where the fetcher should look
+                    }
                 } else {
-                    bail = 1; cnt = -1;                                              // the neighbour's row x is not there yet
+                    cnt = -1;
                 }
             };
             while (true) {
-                x = UNI(x); cnt = UNI(cnt); db = UNI(db); bail = UNI(bail); mlast = UNI(mlast);
+                x = UNI(x); cnt = UNI(cnt); gacc = UNI(gacc); db = UNI(db);
                 const int fl = __builtin_amdgcn_readlane((int)dcf, x & 63);
                 if ((cnt | ~(fl << 31)) < 0) break;
                 fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dcb, (x + 1) & 63));
             }
-            // the last row of a 64-row block (its successor's descriptor is in the next block's registers)
-            if (!bail && (x & 63) == 63 && x < L - 1) {
+            if (!dead && (x & 63) == 63 && x < L - 1) {
                 const int fl = __builtin_amdgcn_readlane((int)dcf, 63);
                 if (fl & 1) {
                     cnt = 0;
                     fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dnb, 0));
-                    if (!bail) V3_ROTATE_BLOCK()
+                    if (!dead) V4_ROTATE_BLOCK()
                 }
             }
-#ifdef PWR_STAMPS
-            const unsigned long long s3_b0 = __builtin_amdgcn_s_memtime();
-#endif
-            if (bail && !dead) {
-#ifdef PWR_STAMPS
-                ++s3_bails;
-#endif
-                // take the unfinished row back, then re-read the group until the neighbour's row x is there
+            if (dead) {                                                              // the unfinished row's C flags
 #pragma unroll
                 for (int i = 0; i < C; ++i) accC[i] >>= 1;
-                const unsigned want = tagbase | (unsigned)(x + 1);
-                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-                while (true) {
-                    V3_LOAD_GROUP(g, cP, cM)
-                    const unsigned tp = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cP), x & (V3_G - 1));
-                    const unsigned tm = (unsigned)__builtin_amdgcn_readlane((int)TAGOF(cM), x & (V3_G - 1));
-                    if (tp == want && tm == want) break;
-                    if (UNI(GLD(abortf)) || __builtin_amdgcn_s_memtime() - t0 > V3_TIMEOUT) { dead = true; V3_SAY(2) break; }
-                    __builtin_amdgcn_s_sleep(4);
-                }
-#ifdef PWR_STAMPS
-                s3_bailwait += __builtin_amdgcn_s_memtime() - s3_b0;
-                const unsigned long long s3_p0 = __builtin_amdgcn_s_memtime();
-#endif
-                // Pacing: go on only when the neighbour is two groups ahead (or done), so that from here on the group
-                // fetched one group early is complete when it arrives -- but only while the neighbour advances: in the
-                // ring it may itself be waiting for this wave (it was the leader, its macro-strip left the band, and its
-                // new one at the far end depends on everybody else), and then there is nothing to wait for.
-                const unsigned need = (unsigned)min(((g + 2) << 4) + 8, L);
-                unsigned seen = 0;
-                unsigned long long t_seen = __builtin_amdgcn_s_memtime();
-                while (!dead) {
-                    const unsigned long long pw = GLD(gprog + wl);
-                    const unsigned have = UNI(TAGOF(pw)) == (tagbase | 1u) ? UNI((unsigned)pw) : 0u;
-                    if (have >= need) break;
-                    const unsigned long long now = __builtin_amdgcn_s_memtime();
-                    if (have != seen) { seen = have; t_seen = now; }
-                    else if (now - t_seen > 16384ull) break;                         // (about ten DP rows' worth of time)
-                    if (UNI(GLD(abortf))) { dead = true; break; }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-#ifdef PWR_STAMPS
-                s3_pace += __builtin_amdgcn_s_memtime() - s3_p0;
-#endif
-                V3_LOAD_GROUP(g, cP, cM)
-                V3_LOAD_GROUP(g + 1, nP, nM)
             }
-#ifdef PWR_STAMPS
-            s3_w = __builtin_amdgcn_s_memtime() - s3_b0; s3_fast += s3_b0 - s3_f0; s3_rows += x - x_in;
-#endif
             if (x != x_in) {
-                if ((x & 15) == 0) {                                                 // the 16-row group is complete
-                    uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;
-#pragma unroll
-                    for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; }
-                    gacc = x >> 4; nacc = 0;
-                    if (lane == 0) GST(gprog + wave, x, 0);                          // progress, for the right neighbour's pacing
-                } else {
-                    nacc = x & 15;
-                }
+                nacc = x & 15;
                 a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
                 sx = __builtin_amdgcn_readlane(scur, x & 63);
-                continue;                                                            // more ordinary rows, most likely
+                if (lane == 0) LST(wprog, x);
+                if (!dead) continue;                                                 // more ordinary rows, most likely
             }
-            if (bail) continue;                                                      // (after the wait) try the row again
         }
-        if (dead) break;
+        if (dead || x >= L) break;
 
         // ---- general path: one row, or one change of macro-strip
-#ifdef PWR_STAMPS
-        s3_t = __builtin_amdgcn_s_memtime();
-#endif
         x = UNI(x); ms = UNI(ms); msn = UNI(msn); a = UNI(a); a_prev = UNI(a_prev); Bx_prev = UNI(Bx_prev);
         sx = UNI(sx); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); gleft = UNI(gleft); gleftn = UNI(gleftn); ran_prev = UNI(ran_prev); cs = UNI(cs);
         const int Bx = min(B, W - a);
         const int ms_lo = (a - lo) / MS, ms_hi = (a + Bx - 1 - lo) / MS;
         if (ms < ms_lo) {
-            // the macro-strip dropped out of the band for good: take over the one NW further right
             ms += NW;
             if (ms == msn) {
 #pragma unroll
@@ -1772,16 +1700,16 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
                 cs ^= 1;
             } else {
                 while (ms < ms_lo) ms += NW;
-                V3_LOADS(ms, cs, ug, gg, ig, gleft)
+                V4_LOADS(ms, cs, ug, gg, ig, gleft)
             }
             msn = ms + NW;
-            V3_LOADS(msn, cs ^ 1, nu, ng, ni, gleftn)
+            V4_LOADS(msn, cs ^ 1, nu, ng, ni, gleftn)
             ran_prev = 0;
             continue;
         }
         if (ms > ms_hi) {                                   // no work for this wave in row x
             ran_prev = 0;
-            V3_NEXT_ROW()
+            V4_NEXT_ROW()
             continue;
         }
         const int y0 = lo + ms * MS;
@@ -1793,22 +1721,17 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
         {
             const unsigned tagx = tagbase | (unsigned)(x + 1), tagp = tagbase | (unsigned)x;
             const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            while (true) {
-                const unsigned long long eP = needP ? GLD(gleftw + 2 * (size_t)x) : 0ull;
-                const unsigned long long eQ = needP ? GLD(gleftw + 2 * (size_t)x + 1) : 0ull;
-                const unsigned long long eM = needM ? GLD(gleftw + 2 * (size_t)(x - 1) + 1) : 0ull;
-                const unsigned long long eT = needT ? GLD(gpt + (x - 1)) : 0ull;
+            for (unsigned spin = 1;; ++spin) {
+                const unsigned long long eQ = LLD(rM[x & (V4_RB - 1)]), eP = LLD(rP[x & (V4_RB - 1)]);
+                const unsigned long long eM = LLD(rM[(x - 1) & (V4_RB - 1)]), eT = LLD(rT[(x - 1) & (V4_RB - 1)]);
                 ePx = UNI((unsigned)eP); ePy = UNI((unsigned)eQ); eMy = UNI((unsigned)eM); eTx = UNI((unsigned)eT);
                 const bool ready = (!needP || (UNI(TAGOF(eP)) == tagx && UNI(TAGOF(eQ)) == tagx)) &&
                                    (!needM || UNI(TAGOF(eM)) == tagp) && (!needT || UNI(TAGOF(eT)) == tagp);
                 if (ready) break;
-                if (UNI(GLD(abortf)) || __builtin_amdgcn_s_memtime() - t0 > V3_TIMEOUT) { dead = true; V3_SAY(4) break; }
-                __builtin_amdgcn_s_sleep(4);
+                if ((spin & 1023u) == 0 && (__builtin_amdgcn_s_memtime() - t0 > V3_TIMEOUT || UNI(GLD(abortf)))) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
             }
             if (dead) break;
-#ifdef PWR_STAMPS
-            s3_genwait += __builtin_amdgcn_s_memtime() - t0;
-#endif
         }
         int Mleft = (int)PWR_INF;
         if (x == 0) Mleft = 0;
@@ -1820,8 +1743,8 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
 #pragma unroll
             for (int i = 0; i < C; ++i) Mprev[i] = (unsigned)(gg[i] + (int)eTx);
         }
-        if ((x >> 4) != gacc) { V3_FLUSH() gacc = x >> 4; }
-        V3_ALIGN_ACC(x & 15)
+        if ((x >> 4) != gacc) { V4_FLUSH() gacc = x >> 4; }
+        V4_ALIGN_ACC(x & 15)
         const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
         const int sxc = min(max(sx, 0), 3);                                      // PW:1503 Score(y, Seq_Bases[x])
         const int rel0 = y0 + lc - a;
@@ -1849,7 +1772,6 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
                 Mprev[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
             }
         } else {
-            // last row: PW:1386 "M == M(x,y-1)" also moves left; keep the row for the entry scan
             unsigned Mn[C];
             unsigned fa = 0;
 #pragma unroll
@@ -1876,16 +1798,10 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
             if (ms == ms_hi) GST(gpt + x, P_end, x);
         }
         ran_prev = 1;
-        V3_NEXT_ROW()
-#ifdef PWR_STAMPS
-        s3_gen += __builtin_amdgcn_s_memtime() - s3_t;
-#endif
+        V4_NEXT_ROW()
     }
-    V3_FLUSH()
-#ifdef PWR_STAMPS
-    if (lane == 0) printf("v3 wave%d L %d total %llu fast %llu (rows %llu entries %llu) bails %llu bailwait %llu pace %llu general %llu (waiting %llu)\n", wave, L, (unsigned long long)(__builtin_amdgcn_s_memtime() - t_clk0), s3_fast, s3_rows, s3_entries, s3_bails, s3_bailwait, s3_pace, s3_gen, s3_genwait);
-#endif
-    if (lane == 0 && !dead) GST(gprog + wave, L, 0);
+    V4_FLUSH()
+    if (lane == 0) LST(wdone, 1);                                                    // releases the fetcher
     if (dead) {
         if (lane == 0) { __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
         return;
@@ -1899,12 +1815,13 @@ __global__ __launch_bounds__(64) void k_fill_v3(DState st, JobBufs jb)
 #undef GLD
 #undef GST
 #undef TAGOF
-#undef V3_LOADS
-#undef V3_LOAD_GROUP
-#undef V3_ALIGN_ACC
-#undef V3_FLUSH
-#undef V3_ROTATE_BLOCK
-#undef V3_NEXT_ROW
+#undef LLD
+#undef LST
+#undef V4_LOADS
+#undef V4_ALIGN_ACC
+#undef V4_FLUSH
+#undef V4_ROTATE_BLOCK
+#undef V4_NEXT_ROW
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2769,9 +2686,9 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
         const size_t nmb = (size_t)njobs * c->wp_waves * jb.Lmax * 2, npt = (size_t)njobs * jb.Lmax;
         if ((rc = dmalloc(c, &jb.gmb, nmb))) return rc;
         if ((rc = dmalloc(c, &jb.gpt, npt))) return rc;
-        if ((rc = dmalloc(c, &jb.gprog, (size_t)njobs * 16))) return rc;
-        if (hipMemset(jb.gmb, 0, nmb * 8) != hipSuccess || hipMemset(jb.gpt, 0, npt * 8) != hipSuccess ||
-            hipMemset(jb.gprog, 0, (size_t)njobs * 16 * 8) != hipSuccess) return PWR_ERR_DEVICE;
+        // on the stream the kernels run on (a plain hipMemset is not ordered against it) and waited for
+        if (hipMemsetAsync(jb.gmb, 0, nmb * 8, c->stream) != hipSuccess || hipMemsetAsync(jb.gpt, 0, npt * 8, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) return PWR_ERR_DEVICE;
         c->fill_epoch = 0;
     }
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
@@ -2784,7 +2701,7 @@ static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
     dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.rec); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
-    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gpt); dfree(c, jb.gprog); dfree(c, c->d_jobrows);
+    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gpt); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -2965,24 +2882,23 @@ static int launch_fill(pwr_ctx *c, int njobs)
         HIPC(hipEventRecord(e0, c->stream));
     }
     if (c->fill_mode == 4) {
-        // one 64-thread work-group per wave; grid.x = 8 keeps the waves of a DP on one XCD (work-groups go to the
-        // XCDs round-robin by linear id)
+        // one work-group (worker + fetcher wave) per wave of the pipeline; grid.x = 8 keeps the work-groups of a DP
+        // on one XCD (work-groups go to the XCDs round-robin by linear id)
         if (++c->fill_epoch >= (1u << 15)) {
             const size_t nmb = (size_t)c->njobs * c->wp_waves * c->jb.Lmax * 2, npt = (size_t)c->njobs * c->jb.Lmax;
             HIPC(hipMemsetAsync(c->jb.gmb, 0, nmb * 8, c->stream));
             HIPC(hipMemsetAsync(c->jb.gpt, 0, npt * 8, c->stream));
-            HIPC(hipMemsetAsync(c->jb.gprog, 0, (size_t)c->njobs * 16 * 8, c->stream));
             c->fill_epoch = 1;
         }
         c->jb.tagbase = c->fill_epoch << 17;
         c->jb.njobs_launched = njobs;
         const dim3 grid(8, c->wp_waves, (njobs + 7) / 8);
-        if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4>), grid, dim3(64), 0, c->stream, c->st, c->jb);
-        else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3>), grid, dim3(64), 0, c->stream, c->st, c->jb);
-        else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6>), grid, dim3(64), 0, c->stream, c->st, c->jb);
-        else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8>), grid, dim3(64), 0, c->stream, c->st, c->jb);
-        else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v3<9, 2>), grid, dim3(64), 0, c->stream, c->st, c->jb);
-        else hipLaunchKernelGGL((k_fill_v3<9, 4>), grid, dim3(64), 0, c->stream, c->st, c->jb);
+        if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v3<9, 2>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else hipLaunchKernelGGL((k_fill_v3<9, 4>), grid, dim3(128), 0, c->stream, c->st, c->jb);
     } else if (c->fill_mode == 3) {
         if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v2<5, 4>), dim3(njobs), dim3(5 * 64), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v2<8, 3>), dim3(njobs), dim3(8 * 64), 0, c->stream, c->st, c->jb);
