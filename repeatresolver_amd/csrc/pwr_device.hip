@@ -1419,7 +1419,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 // neighbour by one poll of the fetcher (a few DP rows), and the L2 round trip is never on its critical path.
 // Ring words keep their row tags, so an old occupant of a slot is never mistaken for the row in demand.
 // ---------------------------------------------------------------------------------------------
-#define V3_TIMEOUT (1ull << 31)                      // shader clocks (about a second) a wave waits for its neighbour
+#define V3_TICKS() ((unsigned)(__builtin_amdgcn_s_memtime() >> 10))   // 32-bit time in units of 1024 shader clocks (scalar compares)
+#define V3_TIMEOUT_TICKS (1u << 21)                  // about a second: how long a wave waits for its neighbour before it flags the job
 #define V4_RB 128                                    // ring slots (rows); the fetcher looks at most 64 rows ahead
 
 template <int NW, int C>
@@ -1455,7 +1456,6 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 
     if (role == 1) {
         // ---- fetcher
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while (true) {
             if (UNI(LLD(wdone))) break;
             const int wx = UNI(LLD(wprog));
@@ -1466,7 +1466,8 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 if (TAGOF(p) == tagr && TAGOF(q) == tagr) { LST(rP[r & (V4_RB - 1)], p); LST(rM[r & (V4_RB - 1)], q); }   // P before M
                 if (TAGOF(t) == tagr) LST(rT[r & (V4_RB - 1)], t);
             }
-            if (UNI(GLD(abortf)) || __builtin_amdgcn_s_memtime() - t0 > 16 * V3_TIMEOUT) break;
+            // (no time-out of its own: the worker has one, and its end -- wdone -- or the job's abort flag end this loop)
+            if (UNI(GLD(abortf))) break;
             __builtin_amdgcn_s_sleep(2);
         }
         return;
@@ -1620,12 +1621,12 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 if (fl & 2) {
                     if (UNI(TAGOF(fM)) != tagx) {
                         // not there yet: wait for the fetcher to deliver it (bounded by a time-out that flags the job)
-                        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                        const unsigned t0 = V3_TICKS();
                         for (unsigned spin = 1;; ++spin) {
                             fM = LLD(rM[x & (V4_RB - 1)]);
                             fP = __hip_atomic_load((unsigned *)&rP[x & (V4_RB - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (UNI(TAGOF(fM)) == tagx) break;
-                            if ((spin & 1023u) == 0 && (__builtin_amdgcn_s_memtime() - t0 > V3_TIMEOUT || UNI(GLD(abortf)))) { dead = true; break; }
+                            if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
                             __builtin_amdgcn_s_sleep(1);
                         }
                     }
@@ -1720,7 +1721,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         unsigned ePx = 0, ePy = 0, eMy = 0, eTx = 0;
         {
             const unsigned tagx = tagbase | (unsigned)(x + 1), tagp = tagbase | (unsigned)x;
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            const unsigned t0 = V3_TICKS();
             for (unsigned spin = 1;; ++spin) {
                 const unsigned long long eQ = LLD(rM[x & (V4_RB - 1)]), eP = LLD(rP[x & (V4_RB - 1)]);
                 const unsigned long long eM = LLD(rM[(x - 1) & (V4_RB - 1)]), eT = LLD(rT[(x - 1) & (V4_RB - 1)]);
@@ -1728,7 +1729,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 const bool ready = (!needP || (UNI(TAGOF(eP)) == tagx && UNI(TAGOF(eQ)) == tagx)) &&
                                    (!needM || UNI(TAGOF(eM)) == tagp) && (!needT || UNI(TAGOF(eT)) == tagp);
                 if (ready) break;
-                if ((spin & 1023u) == 0 && (__builtin_amdgcn_s_memtime() - t0 > V3_TIMEOUT || UNI(GLD(abortf)))) { dead = true; break; }
+                if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
             if (dead) break;
@@ -2516,9 +2517,9 @@ struct pwr_ctx {
     int threads = 256;
     int par_trace = 1;                    // 1: speculative-parallel traceback (k_trace_par), 0: single-wave k_trace_wp
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
-    int fill_mode = 3;
+    int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP), 1: k_fill_wp, 0: k_fill
     unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
-    int wp_waves = 5;                     // waves per DP of the v2 wave pipeline: 9/8/5/4/3 with 2/3/4/6/8 columns per lane                    // 0: LDS-staged fill (k_fill), 1: wave pipeline with polled mailboxes (k_fill_wp), 3: wave pipeline in lock-step rounds (k_fill_v2)
+    int wp_waves = 9;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane
     int cells_per_thread = 1;
     // stats
     pwr_stats stats{};
