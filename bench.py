@@ -74,8 +74,8 @@ def main():
     ap.add_argument("--bandwidth", type=int, default=1000)
     ap.add_argument("--window", type=int, default=None)
     ap.add_argument("--threads", type=int, default=None)
-    ap.add_argument("--fill", type=int, default=None, help="DP fill kernel: 3 lock-step wave pipeline (default), 1 polled wave pipeline, 0 LDS-staged rows")
-    ap.add_argument("--waves", type=int, default=None, help="waves per DP of the v2 fill (9 or 5)")
+    ap.add_argument("--fill", type=int, default=None, help="DP fill kernel: 4 k_fill_v3 one work-group per pipeline wave (default), 3 k_fill_v2 one work-group per DP, 1 polled wave pipeline, 0 LDS-staged rows")
+    ap.add_argument("--waves", type=int, default=None, help="waves per DP of the wave-pipeline fills: 9 (default), 8, 5, 4 or 3")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo for rehearsals)")
@@ -203,7 +203,7 @@ def main():
                          "traffic_unit": "HBM bytes per launch = PMC-measured bytes per cell (profiles/r01_traffic_model.json) "
                                          "x cells of the average launch",
                          "algorithmic_bytes_per_launch": BYTES_PER_CELL * st["cells_computed"] / launches,
-                         "kernel": "k_fill_v2", "launches": st["fill_launches"],
+                         "kernel": {None: "k_fill_v3", 4: "k_fill_v3", 3: "k_fill_v2", 1: "k_fill_wp", 0: "k_fill"}[args.fill], "launches": st["fill_launches"],
                          "avg_launch_ms": st["fill_ms"] / timed,
                          "cells_per_launch": st["cells_computed"] / launches,
                          "note": "achieved = cells computed by k_fill x 4 B / sum of HIP-event launch durations"},
