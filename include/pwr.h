@@ -79,7 +79,7 @@ int pwr_dims(pwr_ctx *ctx, int *rows, int *width);
 /* MMA_Auslesen (PW:1556-1598) into memory: rows*width characters, row-major, no newlines. */
 int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
 
-/* Knobs and counters (ours). keys: "window" (max rows filled speculatively per batch, >= 1),
+/* Knobs and counters (ours). keys: "window" (max rows filled speculatively per batch, 1..128),
  * "profile" (1 = time every fill launch with HIP events), "fill" (DP fill kernel: 4 = k_fill_v3, the default: one
  * work-group per pipeline wave; 3 = k_fill_v2: one work-group per DP; 1 = k_fill_wp; 0 = k_fill),
  * "waves" (waves per DP of the wave-pipeline fills: 9 (default), 8, 5, 4 or 3; bandwidths above 1000 always use 9),

@@ -3149,7 +3149,9 @@ extern "C" int pwr_trim_ends(pwr_ctx *c)
 extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
 {
     if (!c || !key) return PWR_ERR_ARG;
-    if (!strcmp(key, "window")) { if (value < 1 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
+    // (capped: every work-group of a k_fill_v3 launch must be resident at once -- 9 of 128 threads per job -- and a
+    // window beyond what one CU-full of jobs survives is of no use anyway)
+    if (!strcmp(key, "window")) { if (value < 1 || value > 128 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
     if (!strcmp(key, "fill")) { if (c->on_device || (value != 0 && value != 1 && value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "ptrace")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
