@@ -1988,7 +1988,7 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
 //     columns merge within a few rows, so the hand-over chain is short.
 // Results are those of k_trace_wp bit for bit (same per-row step; a step is a function of (row, column)).
 // ---------------------------------------------------------------------------------------------
-#define TRK 8
+#define TRK 16
 #define TR_SPIN_LIMIT (1 << 22)
 __global__ __launch_bounds__(TRK * 64) void k_trace_par(DState st, JobBufs jb)
 {
