@@ -89,7 +89,7 @@ struct JobBufs {
     int *newcol;                   // [njobs][Lmax]   (ordinal << 1) | opened-a-new-column
     int *aux;                      // [njobs][Lmax]   slot of every base after the commit
     unsigned *gbase;               // [njobs][Lmax]   G(anf(x)): per-DP-row base of the prefix sums
-    uint4 *desc;                   // [njobs][Lmax]   per DP row: {anf, Bx | base << 16, wave flags 0-7, wave flags 8-15} (k_fill_v2)
+    uint4 *desc;                   // [njobs][Lmax]   per DP row: {anf | base << 24, flags of waves 0-7, 8-15, 16-23} (4 bits per wave)
     int wpNW, wpMS;                // geometry of the wave pipeline the descriptors are made for
     unsigned *lastM;               // [njobs][NC]     scores of the last DP row (wave-pipeline fill)
     unsigned long long *gmb;       // [njobs][NW][Lmax][2] k_fill_v3: {P_end, tag}, {M_last, tag} per wave and DP row
@@ -281,7 +281,8 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         }
     }
     if (jb.wpNW > 0) {
-        // Row descriptors for k_fill_v2: what every wave would otherwise recompute per DP row.  Wave w owns the
+        // Row descriptors for the wave-pipeline fills: what every wave would otherwise recompute per DP row (anf < 2^24,
+        // the row's base, and per wave 4 flag bits; Bx = min(B, W - anf) is two scalar ops in the kernel).  Wave w owns the
         // macro-strip ms = ms_lo + ((w - ms_lo) mod NW) in row x; 4 flag bits per wave:
         //   bit0 "ordinary row": the wave has work in rows x-1 and x on the same macro-strip, 0 < x < L-1, and the
         //        score left of the macro-strip is not the virtual extension G + Ptot(x-1) of PW:285-295
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
                 plo = (ap - lo) / MSg; phi = (ap + bp - 1 - lo) / MSg;
             }
             unsigned long long fl = 0;
+            unsigned fl2 = 0;                                                       // waves 16..23
             for (int w = 0; w < NWg; ++w) {
                 const int msw = mlo + (((w - mlo) % NWg) + NWg) % NWg;
                 if (msw > mhi) continue;
@@ -307,9 +309,9 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
                 const int yq = lo + msw * MSg - 1;
                 const unsigned kind = (x == 0 || yq < ap) ? 0u : (yq < ap + bp ? 1u : 2u);
                 const unsigned bits = ((ranp && x < L - 1 && kind != 2u) ? 1u : 0u) | (msw > mlo ? 2u : 0u) | (kind == 1u ? 4u : 0u) | (msw == mhi ? 8u : 0u);
-                fl |= (unsigned long long)bits << (4 * w);
+                if (w < 16) fl |= (unsigned long long)bits << (4 * w); else fl2 |= bits << (4 * (w - 16));
             }
-            desc[x] = make_uint4((unsigned)ax, (unsigned)bx | ((unsigned)st.seq[off + x] << 16), (unsigned)fl, (unsigned)(fl >> 32));
+            desc[x] = make_uint4((unsigned)ax | ((unsigned)st.seq[off + x] << 24), (unsigned)fl, (unsigned)(fl >> 32), fl2);
         }
     }
     for (int o = 32; o > 0; o >>= 1) mycells += __shfl_xor(mycells, o);
@@ -1008,10 +1010,9 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     // row descriptors of the gather (64 rows per register, like Way[]): anf, Bx | base << 16, this wave's flags
     const uint4 *desc = jb.desc + (size_t)job * jb.Lmax;
     const int fsh = 4 * (wave & 7);
-    uint4 d4 = desc[min(lane, L - 1)];
-    unsigned dca = d4.x, dcb = d4.y, dcf = (wave < 8 ? d4.z : d4.w) >> fsh;
-    d4 = desc[min(64 + lane, L - 1)];
-    unsigned dna = d4.x, dnb = d4.y, dnz = d4.z, dnw = d4.w;        // (flags picked when the block becomes current: no wait on the load here)
+    const unsigned *descw = (const unsigned *)desc + 1 + (wave >> 3);      // this wave's flag word of a descriptor
+    unsigned dca = desc[min(lane, L - 1)].x, dcf = descw[4 * min(lane, L - 1)] >> fsh;
+    unsigned dna = desc[min(64 + lane, L - 1)].x, dnf = descw[4 * min(64 + lane, L - 1)];      // (shifted when the block becomes current)
     int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H), a_prev = 0, Bx_prev = 0;
     int sx = __builtin_amdgcn_readlane(scur, 0);
     const int max_rounds = 4 * L + 64 * NW + 1024;
@@ -1039,11 +1040,10 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
         if (x < L) {                                                                             \
             if ((x >> 6) != blk) {                                                               \
                 blk = x >> 6;                                                                    \
-                wcur = wnxt; scur = snxt; dca = dna; dcb = dnb; dcf = (wave < 8 ? dnz : dnw) >> fsh; \
+                wcur = wnxt; scur = snxt; dca = dna; dcf = dnf >> fsh; \
                 wnxt = way[min(x + 64 + lane, L - 1)];                                           \
                 snxt = seq[min(x + 64 + lane, L - 1)];                                           \
-                { const uint4 e4_ = desc[min(x + 64 + lane, L - 1)];                             \
-                  dna = e4_.x; dnb = e4_.y; dnz = e4_.z; dnw = e4_.w; }                          \
+                dna = desc[min(x + 64 + lane, L - 1)].x; dnf = descw[4 * min(x + 64 + lane, L - 1)]; \
             }                                                                                    \
             a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);                             \
             sx = __builtin_amdgcn_readlane(scur, x & 63);                                        \
@@ -1078,10 +1078,10 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 const int x_in = x;
                 V2_ALIGN_ACC(x & 15)
                 // the substitution column of the NEXT row is fetched from the LDS table while the current row is computed
-                unsigned db = (unsigned)__builtin_amdgcn_readlane((int)dcb, x & 63);
+                unsigned db = (unsigned)__builtin_amdgcn_readlane((int)dca, x & 63);        // {anf, base << 24} of row x
                 int sgr[C];
 #pragma unroll
-                for (int i = 0; i < C; ++i) sgr[i] = ldsS[wave][cs][min(db >> 16, 3u)][lc + i];
+                for (int i = 0; i < C; ++i) sgr[i] = ldsS[wave][cs][min(db >> 24, 3u)][lc + i];
                 // have the loads above land before the loop, so that the waits inside it are the steady-state ones
 #pragma unroll
                 for (int i = 0; i < C; ++i) asm volatile("" : "+v"(sgr[i]));
@@ -1093,8 +1093,8 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 #endif
                 // One ordinary row.  fl = its flags, dbn = the {Bx, base} descriptor word of the row after it.
                 auto fast_row = [&](const int fl, const unsigned dbn) __attribute__((always_inline)) {
-                    const int af = __builtin_amdgcn_readlane((int)dca, x & 63);
-                    const int Bxf = (int)(db & 0xffffu);
+                    const int af = (int)(db & 0xffffffu);
+                    const int Bxf = min(B, W - af);
                     a_prev = af; Bx_prev = Bxf;                                      // for the general path, should it take the next row
                     db = dbn;
                     const int Mleft_v = (fl & 4) ? (int)mlast_v : (int)PWR_INF;
@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 #define V2_FENCE() __builtin_amdgcn_sched_barrier(0)
                     int incl = run;
                     V2_SCAN_STEP(DPP_ROW_SHR(1), 0xF) V2_FENCE();
-                    const unsigned sxn = min(db >> 16, 3u);
+                    const unsigned sxn = min(db >> 24, 3u);
                     V2_FENCE(); V2_SCAN_STEP(DPP_ROW_SHR(2), 0xF) V2_FENCE();
                     const int *const srow = &ldsS[wave][cs][sxn][lc];
                     const int qs = wave * V2_D + (x & (V2_D - 1));
@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                     const int fl = __builtin_amdgcn_readlane((int)dcf, x & 63);
                     // one exit test (sign bits): no rows left (or the row before gave up) / not an ordinary row (bit 0 clear)
                     if ((cnt | ~(fl << 31)) < 0) break;
-                    fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dcb, (x + 1) & 63));
+                    fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dca, (x + 1) & 63));
                 }
                 // The last row of a 64-row block, if it is an ordinary one as well: its successor's descriptor is in the
                 // registers of the next block, which then become the current ones (as in V2_NEXT_ROW).
@@ -1209,14 +1209,13 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                     const int fl = __builtin_amdgcn_readlane((int)dcf, 63);
                     if (fl & 1) {
                         cnt = 0;
-                        fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dnb, 0));
+                        fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dna, 0));
                         if (!bail) {
                             blk = x >> 6;
-                            wcur = wnxt; scur = snxt; dca = dna; dcb = dnb; dcf = (wave < 8 ? dnz : dnw) >> fsh;
+                            wcur = wnxt; scur = snxt; dca = dna; dcf = dnf >> fsh;
                             wnxt = way[min(x + 64 + lane, L - 1)];
                             snxt = seq[min(x + 64 + lane, L - 1)];
-                            const uint4 e4_ = desc[min(x + 64 + lane, L - 1)];
-                            dna = e4_.x; dnb = e4_.y; dnz = e4_.z; dnw = e4_.w;
+                            dna = desc[min(x + 64 + lane, L - 1)].x; dnf = descw[4 * min(x + 64 + lane, L - 1)];
                         }
                     }
                 }
@@ -1514,10 +1513,9 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
     const uint4 *desc = jb.desc + (size_t)job * jb.Lmax;
     const int fsh = 4 * (wave & 7);
-    uint4 d4 = desc[min(lane, L - 1)];
-    unsigned dca = d4.x, dcb = d4.y, dcf = (wave < 8 ? d4.z : d4.w) >> fsh;
-    d4 = desc[min(64 + lane, L - 1)];
-    unsigned dna = d4.x, dnb = d4.y, dnz = d4.z, dnw = d4.w;
+    const unsigned *descw = (const unsigned *)desc + 1 + (wave >> 3);      // this wave's flag word of a descriptor
+    unsigned dca = desc[min(lane, L - 1)].x, dcf = descw[4 * min(lane, L - 1)] >> fsh;
+    unsigned dna = desc[min(64 + lane, L - 1)].x, dnf = descw[4 * min(64 + lane, L - 1)];      // (shifted when the block becomes current)
     int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H), a_prev = 0, Bx_prev = 0;
     int sx = __builtin_amdgcn_readlane(scur, 0);
 
@@ -1537,11 +1535,10 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 #define V4_ROTATE_BLOCK()                                                                        \
     {                                                                                            \
         blk = x >> 6;                                                                            \
-        wcur = wnxt; scur = snxt; dca = dna; dcb = dnb; dcf = (wave < 8 ? dnz : dnw) >> fsh;     \
+        wcur = wnxt; scur = snxt; dca = dna; dcf = dnf >> fsh;     \
         wnxt = way[min(x + 64 + lane, L - 1)];                                                   \
         snxt = seq[min(x + 64 + lane, L - 1)];                                                   \
-        const uint4 e4_ = desc[min(x + 64 + lane, L - 1)];                                       \
-        dna = e4_.x; dnb = e4_.y; dnz = e4_.z; dnw = e4_.w;                                      \
+        dna = desc[min(x + 64 + lane, L - 1)].x; dnf = descw[4 * min(x + 64 + lane, L - 1)];     \
     }
 #define V4_NEXT_ROW()                                                                            \
     {                                                                                            \
@@ -1568,17 +1565,17 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             const int xstop = UNI(min(L - 1, ((blk + 1) << 6) - 1));
             const int x_in = x;
             V4_ALIGN_ACC(x & 15)
-            unsigned db = (unsigned)__builtin_amdgcn_readlane((int)dcb, x & 63);
+            unsigned db = (unsigned)__builtin_amdgcn_readlane((int)dca, x & 63);        // {anf, base << 24} of row x
             int sgr[C];
 #pragma unroll
-            for (int i = 0; i < C; ++i) sgr[i] = ldsS1[cs][min(db >> 16, 3u)][lc + i];
+            for (int i = 0; i < C; ++i) sgr[i] = ldsS1[cs][min(db >> 24, 3u)][lc + i];
 #pragma unroll
             for (int i = 0; i < C; ++i) asm volatile("" : "+v"(sgr[i]));
             asm volatile("" : "+v"(mlast_v));
             int cnt = xstop - x - 1;
             auto fast_row = [&](const int fl, const unsigned dbn) __attribute__((always_inline)) {
-                const int af = __builtin_amdgcn_readlane((int)dca, x & 63);
-                const int Bxf = (int)(db & 0xffffu);
+                const int af = (int)(db & 0xffffffu);
+                const int Bxf = min(B, W - af);
                 a_prev = af; Bx_prev = Bxf;
                 db = dbn;
                 const int Mleft_v = (fl & 4) ? (int)mlast_v : (int)PWR_INF;
@@ -1604,7 +1601,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 #define V4_FENCE() __builtin_amdgcn_sched_barrier(0)
                 int incl = run;
                 V4_SCAN_STEP(DPP_ROW_SHR(1), 0xF) V4_FENCE();
-                const unsigned sxn = min(db >> 16, 3u);
+                const unsigned sxn = min(db >> 24, 3u);
                 V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(2), 0xF) V4_FENCE();
                 const int *const srow = &ldsS1[cs][sxn][lc];
                 V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(4), 0xF) V4_FENCE();
@@ -1663,13 +1660,13 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 x = UNI(x); cnt = UNI(cnt); gacc = UNI(gacc); db = UNI(db);
                 const int fl = __builtin_amdgcn_readlane((int)dcf, x & 63);
                 if ((cnt | ~(fl << 31)) < 0) break;
-                fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dcb, (x + 1) & 63));
+                fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dca, (x + 1) & 63));
             }
             if (!dead && (x & 63) == 63 && x < L - 1) {
                 const int fl = __builtin_amdgcn_readlane((int)dcf, 63);
                 if (fl & 1) {
                     cnt = 0;
-                    fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dnb, 0));
+                    fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dna, 0));
                     if (!dead) V4_ROTATE_BLOCK()
                 }
             }
@@ -2661,7 +2658,8 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
 {
     JobBufs &jb = c->jb;
     if (c->B > 1000 || (c->fill_mode != 3 && c->fill_mode != 4)) c->wp_waves = 9;
-    const int wpC = c->wp_waves == 8 ? 3 : c->wp_waves == 5 ? 4 : c->wp_waves == 4 ? 6 : c->wp_waves == 3 ? 8 : (c->B <= 1024 ? 2 : 4);
+    if (c->wp_waves == 17 && c->fill_mode != 4) c->wp_waves = 9;          // 17 x 64 threads do not fit one work-group
+    const int wpC = c->wp_waves == 17 ? 1 : c->wp_waves == 8 ? 3 : c->wp_waves == 5 ? 4 : c->wp_waves == 4 ? 6 : c->wp_waves == 3 ? 8 : (c->B <= 1024 ? 2 : 4);
     const int NC = c->fill_mode ? c->wp_waves * 64 * wpC : c->threads * c->cells_per_thread;
     jb.layout = c->fill_mode ? 1 : 0;
     jb.Lmax = std::max(c->Lmax, 1);
@@ -2894,7 +2892,8 @@ static int launch_fill(pwr_ctx *c, int njobs)
         c->jb.tagbase = c->fill_epoch << 17;
         c->jb.njobs_launched = njobs;
         const dim3 grid(8, c->wp_waves, (njobs + 7) / 8);
-        if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        if (c->wp_waves == 17) hipLaunchKernelGGL((k_fill_v3<17, 1>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8>), grid, dim3(128), 0, c->stream, c->st, c->jb);
@@ -3156,7 +3155,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "fill")) { if (c->on_device || (value != 0 && value != 1 && value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "ptrace")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
     if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }
-    if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
+    if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9 && value != 17)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
     if (!strcmp(key, "threads")) {
         if (c->on_device || (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)) return PWR_ERR_ARG;
         c->threads = (int)value;

@@ -75,10 +75,11 @@ def test_row_by_row_against_oracle(name, bw, rounds, fill, oracle):
 
 
 @pytest.mark.parametrize("fill", [4, 3], ids=["v3", "v2"])
-@pytest.mark.parametrize("waves", [3, 4, 5, 8, 9])
+@pytest.mark.parametrize("waves", [3, 4, 5, 8, 9, 17])
 @pytest.mark.parametrize("name,bw,rounds", [STEP_CASES[0], STEP_CASES[4], STEP_CASES[6]], ids=["toy_a_b1000", "lowcov_b300", "deep_b200"])
 def test_wave_geometries_row_by_row(name, bw, rounds, waves, fill, oracle):
-    """All macro-strip widths (3/4/5/8/9 waves per DP) of the two wave-pipeline fill kernels."""
+    """All macro-strip widths (3/4/5/8/9/17 waves per DP) of the two wave-pipeline fill kernels (17 is k_fill_v3 only;
+    k_fill_v2 falls back to 9 there)."""
     _row_by_row(name, bw, rounds, oracle, fill=fill, waves=waves)
 
 
@@ -230,7 +231,7 @@ def test_medium_properties_and_kernel_cross_check():
     from repeatresolver_amd.realigner import PWReAligner
     rows = [bytes(r) for r in dg.make_msa("tree_medium")]
     ref = None
-    for fill, window, waves in ((4, 8, 5), (4, 4, 9), (3, 8, 5), (4, 1, 5), (1, 4, 9), (3, 8, 9), (3, 8, 4)):
+    for fill, window, waves in ((4, 8, 17), (4, 8, 5), (4, 4, 9), (3, 8, 5), (4, 1, 5), (1, 4, 9), (3, 8, 9), (3, 8, 4)):
         g = PWReAligner(rows, bandwidth=1000, fill=fill, window=window, waves=waves)
         g.trim_ends()
         before = [r.replace(b"-", b"").replace(b" ", b"") for r in g.export_rows()]
