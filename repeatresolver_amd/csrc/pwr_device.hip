@@ -1573,10 +1573,11 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             for (int i = 0; i < C; ++i) asm volatile("" : "+v"(sgr[i]));
             asm volatile("" : "+v"(mlast_v));
             int cnt = xstop - x - 1;
+            unsigned goff = (unsigned)x * 16u;                                       // byte offset of row x's words in gmy, kept in a VGPR
+            asm volatile("" : "+v"(goff));
             auto fast_row = [&](const int fl, const unsigned dbn) __attribute__((always_inline)) {
                 const int af = (int)(db & 0xffffffu);
                 const int Bxf = min(B, W - af);
-                a_prev = af; Bx_prev = Bxf;
                 db = dbn;
                 const int Mleft_v = (fl & 4) ? (int)mlast_v : (int)PWR_INF;
                 const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft_v, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
@@ -1610,7 +1611,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(8), 0xF) V4_FENCE();
                 const unsigned tagx = tagbase | (unsigned)(x + 1);
                 V4_FENCE(); V4_SCAN_STEP(DPP_ROW_BCAST15, 0xA) V4_FENCE();
-                unsigned long long *const gq = gmy + 2 * (size_t)x;
+                unsigned long long *const gq = (unsigned long long *)((char *)gmy + goff);      // this row's two words
                 V4_FENCE(); V4_SCAN_STEP(DPP_ROW_BCAST31, 0xC) V4_FENCE();
 #undef V4_SCAN_STEP
 #undef V4_FENCE
@@ -1623,12 +1624,14 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                             fM = LLD(rM[x & (V4_RB - 1)]);
                             fP = __hip_atomic_load((unsigned *)&rP[x & (V4_RB - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (UNI(TAGOF(fM)) == tagx) break;
-                            if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
+                            // time-out: the job is flagged and this loop left after the row -- which is finished with
+                            // whatever is there, nobody will look at the result
+                            if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; cnt = -1; break; }
                             __builtin_amdgcn_s_sleep(1);
                         }
                     }
                 }
-                if (!dead) {
+                {
                     const int P_in_v = (fl & 2) ? (int)fP : PWR_BIG;
                     const int P_end_v = min(P_in_v, incl);
                     int p = min(min(P_in_v, excl), FBIG);
@@ -1645,6 +1648,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                         if (fl & 8) GST(gpt + x, P_end_v, x);
                     }
                     ++x; --cnt;
+                    goff += 16u;
                     if ((x & 15) == 0) {                                             // the 16-row group is complete
                         uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;
 #pragma unroll
@@ -1652,8 +1656,6 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                         gacc = x >> 4;
                         if (lane == 0) LST(wprog, x);                                // where the fetcher should look
                     }
-                } else {
-                    cnt = -1;
                 }
             };
             while (true) {
@@ -1662,14 +1664,17 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 if ((cnt | ~(fl << 31)) < 0) break;
                 fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dca, (x + 1) & 63));
             }
+            int alast = x != x_in ? (__builtin_amdgcn_readlane((int)dca, (x - 1) & 63) & 0xffffff) : a_prev;   // anf of the last row done
             if (!dead && (x & 63) == 63 && x < L - 1) {
                 const int fl = __builtin_amdgcn_readlane((int)dcf, 63);
                 if (fl & 1) {
                     cnt = 0;
+                    alast = (int)(db & 0xffffffu);
                     fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dna, 0));
                     if (!dead) V4_ROTATE_BLOCK()
                 }
             }
+            if (x != x_in) { a_prev = alast; Bx_prev = min(B, W - alast); }         // for the general path, should it take the next row
             if (dead) {                                                              // the unfinished row's C flags
 #pragma unroll
                 for (int i = 0; i < C; ++i) accC[i] >>= 1;
