@@ -95,6 +95,8 @@ struct JobBufs {
     unsigned long long *gmb;       // [njobs][NW][Lmax][2] k_fill_v3: {P_end, tag}, {M_last, tag} per wave and DP row
     unsigned long long *gpt;       // [njobs][Lmax]   k_fill_v3: {Ptot, tag} per DP row
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
+    unsigned long long *gtr;       // [njobs][TRK]    k_trace_par: hand-over words of the chunks
+    unsigned trace_tag;            // 22-bit launch tag of those words
     int njobs_launched;
     int layout;                    // 0: dirs indexed by band cell (y - anf(x)); 1: by (y - lo) mod NC
     int Lmax, colcap, NC;
@@ -1990,19 +1992,20 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
 //     columns merge within a few rows, so the hand-over chain is short.
 // Results are those of k_trace_wp bit for bit (same per-row step; a step is a function of (row, column)).
 // ---------------------------------------------------------------------------------------------
-#define TRK 16
-#define TR_SPIN_LIMIT (1 << 22)
-__global__ __launch_bounds__(TRK * 64) void k_trace_par(DState st, JobBufs jb)
+#define TRK 16                                          // chunks per job ...
+#define TRW 4                                           // ... four to a work-group, so that the chunks of a job spread over four CUs
+#define TR_SPIN_LIMIT (1 << 20)
+// hand-over word of a chunk: [63:42] launch tag, [41:40] 1 = final / 2 = error, [39:24] its 'up' moves, [23:0] exit column + 1
+#define TR_WORD(TAG, FLAG, CNT, Y) (((unsigned long long)(TAG) << 42) | ((unsigned long long)(FLAG) << 40) | ((unsigned long long)((CNT) & 0xffff) << 24) | (unsigned long long)(((Y) + 1) & 0xffffff))
+__global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
 {
-    __shared__ int s_yexit[TRK], s_cnt[TRK];
-    __shared__ int s_flag[TRK];                             // 1 = chunk final, 2 = error
     const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wv = UNI(tid >> 6);
+    const int wv = UNI((int)blockIdx.y * TRW + (tid >> 6));
+    unsigned long long *const hand = jb.gtr + (size_t)job * TRK;
+    const unsigned ttag = jb.trace_tag;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
     if (L <= 0 || !m->ok) return;
-    if (tid < TRK) { s_flag[tid] = 0; s_cnt[tid] = 0; s_yexit[tid] = 0; }
-    __syncthreads();
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -2056,14 +2059,16 @@ __global__ __launch_bounds__(TRK * 64) void k_trace_par(DState st, JobBufs jb)
             }
         } else {
             if (top) break;                                 // already final
+            unsigned long long hw = 0;
             int f = 0;
             for (int spin = 0; spin < TR_SPIN_LIMIT; ++spin) {
-                f = UNI(__hip_atomic_load(&s_flag[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                hw = __hip_atomic_load(&hand[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f = (UNI((unsigned)(hw >> 42)) == ttag) ? (int)(UNI((unsigned)(hw >> 40)) & 3u) : 0;
                 if (f) break;
                 __builtin_amdgcn_s_sleep(2);
             }
             if (f != 1) { err = 5; break; }                 // the chunk above failed (or timed out)
-            y = UNI(__hip_atomic_load(&s_yexit[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            y = (int)(UNI((unsigned)hw) & 0xffffffu) - 1;
             if (y == yguess && xrec_lo <= x_lo) break;      // the guess was right and the whole chunk is recorded
             check_merge = true;
         }
@@ -2196,18 +2201,16 @@ __global__ __launch_bounds__(TRK * 64) void k_trace_par(DState st, JobBufs jb)
     }
     // a guess that broke off early leaves rows below xrec_lo unrecorded: phase 1 retraced through them (no merge
     // is possible there), so every row of the chunk is final now
-    if (lane == 0) {
-        s_yexit[wv] = yout_guess;
-        s_cnt[wv] = cnt;
-        __hip_atomic_store(&s_flag[wv], err ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    if (lane == 0)
+        __hip_atomic_store(&hand[wv], TR_WORD(ttag, err ? 2 : 1, cnt, yout_guess), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (err) {
         if (lane == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
         return;
     }
     if (wv == 0 && lane == 0) {
-        int tot = 0;
-        for (int c = 0; c < nch; ++c) tot += s_cnt[c];     // all chunks above are final (hand-over order)
+        int tot = cnt;
+        for (int c = 1; c < nch; ++c)                       // all chunks above are final (hand-over order) and posted
+            tot += (int)((__hip_atomic_load(&hand[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 24) & 0xffffull);
         m->nnew = tot;
     }
 }
@@ -2520,6 +2523,7 @@ struct pwr_ctx {
     int par_trace = 1;                    // 1: speculative-parallel traceback (k_trace_par), 0: single-wave k_trace_wp
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP), 1: k_fill_wp, 0: k_fill
+    unsigned trace_epoch = 0;             // k_trace_par launch counter (22 bits)
     unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
     int wp_waves = 9;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane
     int cells_per_thread = 1;
@@ -2695,6 +2699,9 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
             hipStreamSynchronize(c->stream) != hipSuccess) return PWR_ERR_DEVICE;
         c->fill_epoch = 0;
     }
+    if ((rc = dmalloc(c, &jb.gtr, (size_t)njobs * 16))) return rc;
+    if (hipMemsetAsync(jb.gtr, 0, (size_t)njobs * 16 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
+    c->trace_epoch = 0;
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
     if (hipMemset(jb.meta, 0, sizeof(JobMeta) * njobs) != hipSuccess) return PWR_ERR_DEVICE;
     c->njobs = njobs;
@@ -2705,7 +2712,7 @@ static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
     dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.rec); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
-    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gpt); dfree(c, c->d_jobrows);
+    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gpt); dfree(c, jb.gtr); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -3011,7 +3018,11 @@ static int run_batch(pwr_ctx *c, int k0, int n, int *done)
     if (rc) return rc;
     hipLaunchKernelGGL(k_gather, dim3(n), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids + k0);
     if ((rc = launch_fill(c, n))) return rc;
-    if (c->fill_mode && c->par_trace) hipLaunchKernelGGL(k_trace_par, dim3(n), dim3(TRK * 64), 0, c->stream, c->st, c->jb);
+    if (c->fill_mode && c->par_trace) {
+        if (++c->trace_epoch >= (1u << 22)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * 16 * 8, c->stream)); c->trace_epoch = 1; }
+        c->jb.trace_tag = c->trace_epoch;
+        hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
+    }
     else if (c->fill_mode) hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
     else hipLaunchKernelGGL(k_trace, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
     hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n);
