@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 // Ring words keep their row tags, so an old occupant of a slot is never mistaken for the row in demand.
 // ---------------------------------------------------------------------------------------------
 #define V3_TICKS() ((unsigned)(__builtin_amdgcn_s_memtime() >> 10))   // 32-bit time in units of 1024 shader clocks (scalar compares)
-#define V3_TIMEOUT_TICKS (1u << 21)                  // about a second: how long a wave waits for its neighbour before it flags the job
+#define V3_TIMEOUT_TICKS (1u << 23)                  // a few seconds: how long a wave waits for its neighbour before it flags the job
 #define V4_RB 128                                    // ring slots (rows); the fetcher looks at most 64 rows ahead
 
 template <int NW, int C>
@@ -3171,6 +3171,9 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "fill")) { if (c->on_device || (value != 0 && value != 1 && value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "ptrace")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
     if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }
+    // (test hooks: where the launch counters behind the mailbox / hand-over tags stand, so that their wrap-around can be exercised)
+    if (!strcmp(key, "fill_epoch")) { if (value < 0 || value >= (1 << 15)) return PWR_ERR_ARG; c->fill_epoch = (unsigned)value; return PWR_OK; }
+    if (!strcmp(key, "trace_epoch")) { if (value < 0 || value >= (1 << 22)) return PWR_ERR_ARG; c->trace_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9 && value != 17)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
     if (!strcmp(key, "threads")) {
         if (c->on_device || (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)) return PWR_ERR_ARG;

@@ -47,6 +47,10 @@ class PWReAligner:
         if profile:
             _check(self._lib.pwr_set_option(self._h, b"profile", 1), "set profile")
 
+    def set_option(self, key, value):
+        """pwr_set_option (include/pwr.h); most knobs must be set before the first call that touches the device."""
+        _check(self._lib.pwr_set_option(self._h, key.encode(), int(value)), "set " + key)
+
     @classmethod
     def from_file(cls, path, **kw):
         with open(path, "rb") as f:

@@ -106,6 +106,28 @@ def test_batched_rounds_match_sequential_oracle(window, fill, oracle):
         g.close()
 
 
+def test_launch_tag_wraparound(oracle):
+    """The mailbox words of k_fill_v3 and the hand-over words of k_trace_par carry a launch counter; when it wraps
+    the arrays are cleared and counting restarts.  Start both counters just below their limits."""
+    from repeatresolver_amd.realigner import PWReAligner
+    name, bw = "lowcov_b300", 300
+    rows = split_rows(golden_input(name))
+    g = PWReAligner(rows, bandwidth=bw, window=3)
+    g.trim_ends()
+    g.total_score()                                  # first device call: allocates, counters at 0
+    g.set_option("fill_epoch", (1 << 15) - 5)
+    g.set_option("trace_epoch", (1 << 22) - 7)
+    h = oracle.create(rows, bw)
+    oracle.lib.pwo_trim(h)
+    for _ in range(2):
+        g.realign_round()
+        oracle.lib.pwo_realign_round(h)
+        assert g.total_score() == oracle.lib.pwo_total_score(h)
+        assert g.export_rows() == oracle.export(h)
+    oracle.lib.pwo_destroy(h)
+    g.close()
+
+
 def test_seeded_round_parity_and_invariants(oracle):
     """Fresh seeded input (not a fixture): two whole rounds through pwr_realign_round."""
     from repeatresolver_amd import datagen as dg
