@@ -42,6 +42,7 @@ struct Hdr {                       // lives in device memory, one per context
     unsigned long long cells_reference;
     unsigned long long rows_changed;   // commits that changed at least one column
     unsigned long long fail_reason[4]; // why speculative jobs were rejected: 0 ends/length, 1 left clamp, 2 right clamp, 3 newer column
+    int agree, pad0;               // the two order buffers hold the same ordinals for the columns [0, agree)
 };
 
 struct Tally {                     // 32 B per column slot
@@ -2256,7 +2257,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     const int nfree = h->nfree, nslots = h->nslots;
     const int take = min(nnew, nfree);
     const unsigned newver = (unsigned)h->version + 1u;
-    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[3] = 0; }    // [0] freed slots, [1] some column lost its last base, [3] any change
+    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[3] = 0; s_i[4] = 0x7fffffff; }   // [0] freed slots, [1] some column lost its last base, [3] any change, [4] first ordinal that changes
     for (int y = ny0 + tid; y <= nyL; y += COMMIT_NT) mark2[y - lo] = 0;
     __syncthreads();
     for (int x = tid; x < L; x += COMMIT_NT) {
@@ -2292,6 +2293,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
                 st.tally[slot] = nt;
                 st.colver[slot] = newver;
                 atomicAdd(&st.inscnt[y], 1);
+                atomicMin(&s_i[4], y);
                 aux[x] = slot;
             } else {
                 aux[x] = sloty;
@@ -2317,7 +2319,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
             }
             st.colver[slot] = newver;
             s_i[3] = 1;
-            if (w4 == 0) s_i[1] = 1;
+            if (w4 == 0) { s_i[1] = 1; atomicMin(&s_i[4], y); }
         }
     }
     for (int x = tid; x < L; x += COMMIT_NT) st.pos[off + x] = aux[x];
@@ -2329,9 +2331,12 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     const bool restructure = (nnew > 0) || (s_i[1] != 0);
     int Wnew = W;
     if (restructure) {
-        // 3. W_Con (PW:706-763) + splice: new ordinal of every surviving / new column
-        carry = 0;
-        for (int base = 0; base < W; base += COMMIT_NT) {
+        // 3. W_Con (PW:706-763) + splice: new ordinal of every surviving / new column.  Columns left of the first one
+        //    that changes keep their ordinal, and the other order buffer already holds them as far as the two agree,
+        //    so the renumbering starts there (rows are realigned left to right: on average half the width is skipped)
+        const int s0 = max(0, min(s_i[4], h->agree));
+        carry = (unsigned)s0;
+        for (int base = s0; base < W; base += COMMIT_NT) {
             const int y = base + tid;
             const bool valid = y < W;
             const int slot = valid ? order[y] : 0;
@@ -2371,6 +2376,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
             h->nslots = nslots + (nnew - take);
             h->nfree = nfree - take + s_i[0];
             h->cur = cur ^ 1;
+            h->agree = max(0, min(s_i[4], W));
         }
         h->version = (int)newver;
         h->cells_reference += m->cells;
@@ -2430,7 +2436,7 @@ __device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsig
 __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs jb, int njobs)
 {
     __shared__ unsigned sh[COMMIT_NT / 64];
-    __shared__ int s_i[4];
+    __shared__ int s_i[8];
     Hdr *h = st.hdr;
     if (threadIdx.x == 0) { h->ncommitted = 0; h->stop = 0; }
     __syncthreads();
@@ -2774,7 +2780,7 @@ static int upload(pwr_ctx *c)
     st.slotcap = st.colcap;
     int rc;
     Hdr hdr{};
-    hdr.W = W; hdr.nslots = W; hdr.nfree = 0; hdr.cur = 0;
+    hdr.W = W; hdr.nslots = W; hdr.nfree = 0; hdr.cur = 0; hdr.agree = 0;
     long long *d_rowoff; int *d_rowlen; uint8_t *d_seq;
     if ((rc = dmalloc(c, &st.hdr, 1))) return rc;
     if ((rc = dmalloc(c, &d_rowoff, T + 1))) return rc;
