@@ -68,6 +68,14 @@ def test_argument_and_input_errors(tmp_path):
     assert e.value.code == -5
     with pytest.raises(PwrError):
         PWReAligner([b"acgt"], bandwidth=0)
+    g = PWReAligner([b"acgt", b"ac-t"])                    # option ranges (no device call is made)
+    for key, bad in (("window", 0), ("window", 129), ("fill", 2), ("fill", 5), ("waves", 7), ("waves", 16), ("nonsense", 1)):
+        with pytest.raises(PwrError) as e:
+            g.set_option(key, bad)
+        assert e.value.code == -1, (key, bad)
+    for key, good in (("window", 128), ("fill", 3), ("fill", 4), ("waves", 17), ("waves", 9), ("ptrace", 0), ("ptrace", 1)):
+        g.set_option(key, good)
+    g.close()
     lib = _lib.load()
     lib.pwr_read_msa_file.restype = ctypes.c_int
     lib.pwr_read_msa_file.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
