@@ -1,11 +1,18 @@
 #!/usr/bin/env python3
 """bench.py -- sum-of-pairs DP cells/s of the MI355X PW_ReAligner hot path.
 
-A "step" is one full realignment round (every row of the MSA once, PW_ReAligner.c:1695-1737) over
-a synthetic MSA that is resident in HBM when the timed region starts.  At N=1 the workload is
-BASELINE.json configs[1]: the DataSimulator-default Tree_1perc_30000kb MSA (100 copies, 40x, 30 kb).
-With N>1 every rank realigns its own, independent MSA of the same shape (weak scaling; the path
-shards by MSA / section with no data-path collective).
+The workload is BASELINE.json configs[1]: the DataSimulator-default Tree_1perc_30000kb MSA (100 copies, 40x,
+30 kb; 13 510 rows x 136 477 columns here), resident in HBM when the timed region starts.  One full realignment
+round of it (PW_ReAligner.c:1695-1737) takes tens of seconds, so a "step" is a SLAB of that round: the next
+T/8 rows in input order (pwr_realign_rows, a partial k loop of PW:1695).  Slabs follow each other through the
+round and on into the next rounds, exactly as the reference's loop would visit the rows, so K steps are K/8
+rounds of the real computation.  `value` = DP cells the reference would have filled for the rows realigned in
+the timed steps / wall time.
+
+N > 1 (one process per GPU, torch.distributed): BASELINE.json configs[3] -- ONE MSA of the same shape is cut
+into its Window.py sections (repeatresolver_amd/window.py), the sections are dealt to the ranks (no data-path
+collective: a section is an independent MSA), a step realigns the next slab of every section, and the
+totals are reduced over RCCL.  Fixed total work => "scaling": "strong".
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -15,23 +22,28 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
+T_START = time.time()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_CELL = 4.0           # algorithmic bytes per DP cell (one 32-bit score per cell)
+FILL_KERNELS = {5: "k_fill_sk", 4: "k_fill_v3", 3: "k_fill_v2"}
 
 
-def measured_traffic_per_cell():
-    """HBM bytes per computed DP cell of the fill kernel, from the committed rocprofv3 PMC passes
-    (profiles/r01_traffic_model.json: 2 x FETCH_SIZE + WRITE_SIZE over the cells of the same run)."""
+def measured_traffic():
+    """HBM bytes per fill launch from a rocprofv3 --pmc run of THIS command (scripts/pmc_bench.sh writes
+    profiles/bench_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).  None when no such
+    measurement is committed -- it is never modelled."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic_model.json")) as f:
-            return float(json.load(f)["hbm_bytes_per_cell"])
+        with open(os.path.join(ROOT, "profiles", "bench_traffic.json")) as f:
+            d = json.load(f)
+        return float(d["hbm_bytes_per_launch"]), d.get("command")
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(rows, bandwidth, budget_s=15.0):
@@ -65,18 +77,27 @@ def cpu_baseline(rows, bandwidth, budget_s=15.0):
                       f"oracle/pw_oracle.c -O2, array-based restatement pinned to the reference by tests/golden)"}
 
 
+def slab_bounds(T, slabs, i):
+    """Rows [k0, k1) of step i: slab i mod slabs of round i // slabs."""
+    s = i % slabs
+    return (s * T) // slabs, ((s + 1) * T) // slabs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="tree_default")
     ap.add_argument("--bandwidth", type=int, default=1000)
+    ap.add_argument("--slabs", type=int, default=8, help="steps per realignment round (a step = T/slabs consecutive rows)")
+    ap.add_argument("--sections", type=int, default=6, help="N > 1: Window.py parts the MSA is cut into (configs[3]: 6)")
     ap.add_argument("--window", type=int, default=None)
-    ap.add_argument("--threads", type=int, default=None)
-    ap.add_argument("--fill", type=int, default=None, help="DP fill kernel: 4 k_fill_v3 one work-group per pipeline wave (default), 3 k_fill_v2 one work-group per DP, 1 polled wave pipeline, 0 LDS-staged rows")
-    ap.add_argument("--waves", type=int, default=None, help="waves per DP of the wave-pipeline fills: 9 (default), 8, 5, 4 or 3")
+    ap.add_argument("--fill", type=int, default=None, help="DP fill kernel (see include/pwr.h)")
+    ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--deadline-s", type=float, default=500.0,
+                    help="N = 1: once the process has run this long, the line is printed for the steps finished so far (no further step is started)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="process-group backend for --gpus > 1 (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal on a 1-GPU box: every rank uses device 0")
@@ -98,13 +119,14 @@ def main():
 
     from repeatresolver_amd import datagen as dg
     from repeatresolver_amd.realigner import PWReAligner
+    from repeatresolver_amd.window import slice_sections, window_boundaries
 
     def note(msg):
         if rank == 0:
-            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+            print(f"[bench {time.strftime('%H:%M:%S')} +{time.time() - T_START:.0f}s] {msg}", file=sys.stderr, flush=True)
 
     cfg = dg.CONFIGS[args.workload]
-    cfg = dg.SimConfig(**{**cfg.__dict__, "seed": args.seed + rank})
+    cfg = dg.SimConfig(**{**cfg.__dict__, "seed": args.seed})     # every rank generates the SAME MSA
     t0 = time.time()
     msa = dg.build_msa(dg.simulate(cfg))
     rows = [bytes(r) for r in msa]
@@ -113,106 +135,157 @@ def main():
     gen_s = time.time() - t0
     note(f"generated {T} rows x {W0} columns in {gen_s:.1f} s")
 
-    g = PWReAligner(rows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, threads=args.threads, fill=args.fill, waves=args.waves)
-    g.trim_ends()
-    score0 = g.total_score()            # first device call: uploads the MSA into HBM
+    # ---- the units this rank owns
+    if world == 1:
+        units = [("whole MSA", rows)]
+        bounds = None
+    else:
+        bounds = window_boundaries(rows, parts=args.sections)                 # Window.py:41-60
+        secs = slice_sections(rows, bounds)
+        # longest-processing-time deal by bases per section: identical on every rank
+        cost = [sum(len(r) - r.count(b"-") - r.count(b" ") for r in s) for s in secs]
+        load = [0] * world
+        owner = [0] * len(secs)
+        for p in sorted(range(len(secs)), key=lambda p: -cost[p]):
+            r = min(range(world), key=lambda r: (load[r], r))
+            owner[p] = r
+            load[r] += cost[p]
+        units = [(f"section {p} columns [{bounds[p]},{bounds[p + 1]})", secs[p]) for p in range(len(secs)) if owner[p] == rank]
+        note(f"sections {bounds} dealt as {owner}")
+    ctxs = []
+    score0 = 0
+    for _, urows in units:
+        g = PWReAligner(urows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, fill=args.fill, waves=args.waves)
+        g.trim_ends()
+        score0 += g.total_score()            # first device call: uploads the MSA into HBM
+        ctxs.append(g)
     note(f"resident in HBM, score {score0}")
 
-    def run_round(tag):
-        """One realignment round with a heartbeat on stderr (a full-size round runs for minutes)."""
-        import threading
-        done = threading.Event()
-
-        def beat():
-            t_start = time.time()
-            while not done.wait(60.0):
-                note(f"{tag}: still running, {time.time() - t_start:.0f} s")
-        th = threading.Thread(target=beat, daemon=True)
-        th.start()
-        try:
-            g.realign_round()
-        finally:
-            done.set()
-            th.join()
-
-    for i in range(args.warmup):
-        run_round(f"warm-up round {i + 1}")
-        note(f"warm-up round {i + 1} done")
-    g.reset_stats()
+    def run_step(i):
+        k0, k1 = slab_bounds(T, args.slabs, i)
+        if len(ctxs) == 1:
+            ctxs[0].realign_rows(k0, k1 - k0)
+        elif ctxs:
+            ths = [threading.Thread(target=g.realign_rows, args=(k0, k1 - k0)) for g in ctxs]   # the C calls release the GIL
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_round(f"timed round {i + 1}")
-        note(f"timed round {i + 1} done")
-    fence()
-    dt = time.perf_counter() - t0
-    st = g.stats()
-    clk_mhz, fill_us = g.debug_fill_clock()
-    dbg = g.debug_last_job(cap=4)
-    print("debug: last job L=%d fill_us=%.1f clk=%.0f MHz rounds=%d" % (dbg["L"], fill_us, clk_mhz, dbg.get("rounds", -1)), file=sys.stderr)
-    score1 = g.total_score()
-    _, W1 = g.dims()
+    def stats_sum():
+        tot = {}
+        for g in ctxs:
+            st = g.stats()
+            for k_, v in st.items():
+                if isinstance(v, list):
+                    tot[k_] = [a + b for a, b in zip(tot.get(k_, [0] * len(v)), v)]
+                else:
+                    tot[k_] = tot.get(k_, 0) + v
+        return tot
 
-    cells = float(st["cells_reference"])
-    tmax, csum = dt, cells
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        cs = torch.tensor([cells], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(cs, op=dist.ReduceOp.SUM)
-        tmax, csum = float(t.item()), float(cs.item())
-
-    if rank == 0:
+    def report(steps_done, dt, final):
+        """Builds and prints THE json line (rank 0)."""
+        st = stats_sum() if ctxs else {"cells_reference": 0, "cells_computed": 0, "fill_ms": 0.0, "fill_launches": 0, "fill_launches_timed": 0,
+                                       "rows_committed": 0, "rows_recomputed": 0, "batches": 0, "rows_changed": 0, "reject_reason": [0, 0, 0, 0]}
+        cells = float(st["cells_reference"])
+        tmax, csum, tmin = dt, cells, dt
+        per_rank = None
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            ts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(ts, t)
+            cs = torch.tensor([cells], dtype=torch.float64, device=red_dev)
+            css = [torch.zeros_like(cs) for _ in range(world)]
+            dist.all_gather(css, cs)
+            per_rank = [{"rank": r, "seconds": float(ts[r].item()), "cells": float(css[r].item())} for r in range(world)]
+            tmax = max(p["seconds"] for p in per_rank)
+            csum = sum(p["cells"] for p in per_rank)
+        if rank != 0:
+            return
         fill_s = st["fill_ms"] / 1e3
         launches = max(1, st["fill_launches"])
         timed = max(1, st["fill_launches_timed"])
-        # all launches are timed unless there were more than 65536 of them; scale the cells accordingly
-        cells_timed = st["cells_computed"] * (timed / launches)
+        cells_timed = st["cells_computed"] * (timed / launches)     # all launches are timed unless there were > 65536 of them
         achieved = (cells_timed * BYTES_PER_CELL / fill_s / 1e9) if fill_s > 0 else 0.0
+        traffic, traffic_cmd = measured_traffic()
+        score1 = sum(g.total_score() for g in ctxs)
+        W1 = sum(g.dims()[1] for g in ctxs)
+        if world == 1:
+            wl = (f"{cfg.name} ({args.workload}: {cfg.kind}, {cfg.copies} copies, {cfg.coverage:g}x, {cfg.repeat_len} bp; reads simulated with "
+                  f"DataSimulator.py's distributions, seed {cfg.seed}; the MSA stacks the TRUE read-to-template alignments with InitialAligner's "
+                  f"layout rule -- it is not an InitialAligner product) -> {T} rows x {W0} columns, bandwidth {args.bandwidth}; one step = "
+                  f"{args.slabs}th of a realignment round = {T // args.slabs} consecutive rows, steps continue through successive rounds")
+        else:
+            wl = (f"{cfg.name} as above ({T} rows x {W0} columns, truth-stacked) cut into {args.sections} Window.py sections {bounds}, sections dealt to "
+                  f"{world} ranks by bases; one step = the next {T // args.slabs} rows of every section")
         out = {
             "metric": "sum-of-pairs DP cells/sec",
-            "value": csum / tmax,
+            "value": csum / tmax if tmax > 0 else 0.0,
             "unit": "DP cells/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps_done,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * tmax / max(1, args.steps),
+            "ms_per_step": 1e3 * tmax / max(1, steps_done),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak" if world == 1 else "strong",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"{cfg.name} ({args.workload}: {cfg.kind}, {cfg.copies} copies, {cfg.coverage:g}x, "
-                                   f"{cfg.repeat_len} bp) -> {T} rows x {W0} columns per GPU, bandwidth {args.bandwidth}, "
-                                   f"one step = one realignment round",
-                       "rows": T, "columns_in": W0, "columns_now": W1, "bandwidth": args.bandwidth,
-                       "window": args.window, "score_before": score0, "score_after": score1,
-                       "rows_committed": st["rows_committed"], "rows_recomputed": st["rows_recomputed"], "batches": st["batches"], "rows_changed": st["rows_changed"], "reject_reason": st["reject_reason"],
-                       "fill_threads": args.threads, "shader_clock_mhz_last_fill": round(clk_mhz),
-                       "generate_s": round(gen_s, 1)},
+            "config": {"workload": wl, "rows": T, "columns_in": W0, "columns_now": W1, "bandwidth": args.bandwidth,
+                       "slabs_per_round": args.slabs, "rounds_timed": steps_done / args.slabs,
+                       "score_before": score0, "score_after": score1,
+                       "rows_committed": st["rows_committed"], "rows_recomputed": st["rows_recomputed"], "batches": st["batches"],
+                       "rows_changed": st["rows_changed"], "reject_reason": st["reject_reason"],
+                       "generate_s": round(gen_s, 1), "complete": bool(final)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (None if measured_traffic_per_cell() is None
-                                     else measured_traffic_per_cell() * st["cells_computed"] / launches),
-                         "traffic_unit": "HBM bytes per launch = PMC-measured bytes per cell (profiles/r01_traffic_model.json) "
-                                         "x cells of the average launch",
+                         "traffic": traffic,
+                         "traffic_note": (f"HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of `{traffic_cmd}` (profiles/bench_traffic.json)"
+                                          if traffic is not None else "no PMC pass of this command is committed"),
                          "algorithmic_bytes_per_launch": BYTES_PER_CELL * st["cells_computed"] / launches,
-                         "kernel": {None: "k_fill_v3", 4: "k_fill_v3", 3: "k_fill_v2", 1: "k_fill_wp", 0: "k_fill"}[args.fill], "launches": st["fill_launches"],
+                         "kernel": FILL_KERNELS.get(ctxs[0].get_option("fill") if ctxs else 4, "k_fill"),
+                         "launches": st["fill_launches"], "launches_timed": st["fill_launches_timed"],
                          "avg_launch_ms": st["fill_ms"] / timed,
                          "cells_per_launch": st["cells_computed"] / launches,
-                         "note": "achieved = cells computed by k_fill x 4 B / sum of HIP-event launch durations"},
+                         "cells_reference": st["cells_reference"], "cells_computed": st["cells_computed"],
+                         "note": "achieved = DP cells computed by the fill kernel (speculative ones included) x 4 B / sum of HIP-event "
+                                 "durations of its launches on the context's stream (rank 0's contexts)"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+        if world == 1 and not args.no_cpu_baseline and final:
             note("timing the CPU baseline on a bounded sample")
             out["cpu_baseline"] = cpu_baseline(rows, args.bandwidth)
+        elif world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    g.close()
+
+    for i in range(args.warmup):
+        run_step(i)
+        note(f"warm-up step {i + 1}/{args.warmup} done")
+    for g in ctxs:
+        g.reset_stats()
+    fence()
+    t0 = time.perf_counter()
+    done = 0
+    for i in range(args.steps):
+        run_step(args.warmup + i)
+        done = i + 1
+        note(f"timed step {done}/{args.steps} done, {time.perf_counter() - t0:.1f} s")
+        # A kill at the driver's limit must not leave the run without its line: past the deadline, report what is there.
+        if world == 1 and done < args.steps and time.time() - T_START > args.deadline_s:
+            note(f"deadline: reporting {done} finished steps")
+            break
+    fence()
+    dt = time.perf_counter() - t0
+    report(done, dt, final=(done == args.steps))
+    for g in ctxs:
+        g.close()
     if world > 1:
         dist.destroy_process_group()
 

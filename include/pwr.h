@@ -72,6 +72,9 @@ int pwr_realign_row(pwr_ctx *ctx, int k);
  * calling pwr_realign_row for k = 0..rows-1; internally upcoming rows are filled speculatively and
  * committed in order. */
 int pwr_realign_round(pwr_ctx *ctx);
+/* A slab of that k-loop: rows k0 .. k0+n-1 in input order (a partial PW:1695 loop).  Calling it for consecutive
+ * slabs that cover 0..rows-1 equals pwr_realign_round; speculation stays inside the slab. */
+int pwr_realign_rows(pwr_ctx *ctx, int k0, int n);
 /* The integer total that OverallScorePrint prints (PW:864-892, PW:933-963); compacts first. */
 int pwr_total_score(pwr_ctx *ctx, uint64_t *total);
 /* Tiefe / current Breite (PW:86-87). */
@@ -89,6 +92,7 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
  * the device arrays are (re)allocated).  "fill", "waves", "threads" and "slack" must be set before the first call
  * that touches the device. */
 int pwr_set_option(pwr_ctx *ctx, const char *key, long value);
+int pwr_get_option(pwr_ctx *ctx, const char *key, long *value);
 int pwr_get_stats(pwr_ctx *ctx, pwr_stats *out);
 int pwr_reset_stats(pwr_ctx *ctx);
 const char *pwr_strerror(int code);

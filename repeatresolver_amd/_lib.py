@@ -16,8 +16,8 @@ class PwrStats(ctypes.Structure):
 
 
 # every symbol include/pwr.h declares
-EXPORTS = ["pwr_create", "pwr_destroy", "pwr_trim_ends", "pwr_realign_row", "pwr_realign_round",
-           "pwr_total_score", "pwr_dims", "pwr_export_rows", "pwr_set_option", "pwr_get_stats",
+EXPORTS = ["pwr_create", "pwr_destroy", "pwr_trim_ends", "pwr_realign_row", "pwr_realign_round", "pwr_realign_rows",
+           "pwr_total_score", "pwr_dims", "pwr_export_rows", "pwr_set_option", "pwr_get_option", "pwr_get_stats",
            "pwr_reset_stats", "pwr_strerror", "pwr_device_count", "pwr_read_msa_file",
            "pwr_write_msa_file", "pwr_run_file"]
 
@@ -43,6 +43,8 @@ def load():
         getattr(lib, n).argtypes = [vp]
     lib.pwr_realign_row.restype = ci
     lib.pwr_realign_row.argtypes = [vp, ci]
+    lib.pwr_realign_rows.restype = ci
+    lib.pwr_realign_rows.argtypes = [vp, ci, ci]
     lib.pwr_total_score.restype = ci
     lib.pwr_total_score.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64)]
     lib.pwr_dims.restype = ci
@@ -51,6 +53,8 @@ def load():
     lib.pwr_export_rows.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t]
     lib.pwr_set_option.restype = ci
     lib.pwr_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_long]
+    lib.pwr_get_option.restype = ci
+    lib.pwr_get_option.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)]
     lib.pwr_get_stats.restype = ci
     lib.pwr_get_stats.argtypes = [vp, ctypes.POINTER(PwrStats)]
     lib.pwr_strerror.restype = ctypes.c_char_p

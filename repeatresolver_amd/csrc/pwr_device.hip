@@ -3057,29 +3057,46 @@ extern "C" int pwr_realign_row(pwr_ctx *c, int k)
     return check_status(c);
 }
 
-extern "C" int pwr_realign_round(pwr_ctx *c)
+// Rows k0 .. k0+n-1 in input order (a slab of the k loop, PW:1695-1737), speculative batches inside the slab only.
+static int realign_range(pwr_ctx *c, int k0, int n)
 {
-    if (!c) return PWR_ERR_ARG;
-    int rc = ensure_device(c);
-    if (rc) return rc;
-    int k = 0;                                                                 // PW:1695: rows in input order
+    int k = k0;
+    const int kend = k0 + n;
     double ema = c->batch_ema;
-    while (k < c->T) {
+    int rc;
+    while (k < kend) {
         // A batch costs as long as its longest fill; rows that overlap the rows before them are almost
         // always invalidated while the MSA is still moving, so speculate just past the running mean.
-        int n = (int)(ema + 2.6);
-        n = std::max(1, std::min(n, std::min(c->window, c->T - k)));
+        int nb = (int)(ema + 2.6);
+        nb = std::max(1, std::min(nb, std::min(c->window, kend - k)));
         // ... and never let a speculative row make the batch longer than its first row, the only one
         // that is certain to commit: a fill takes time proportional to the row's length
-        for (int j = 1; j < n; ++j)
-            if (c->rowlen[k + j] > c->rowlen[k] + c->rowlen[k] / 16 + 64) { n = j; break; }
+        for (int j = 1; j < nb; ++j)
+            if (c->rowlen[k + j] > c->rowlen[k] + c->rowlen[k] / 16 + 64) { nb = j; break; }
         int done = 0;
-        if ((rc = run_batch(c, k, n, &done))) return rc;
+        if ((rc = run_batch(c, k, nb, &done))) return rc;
         ema = 0.75 * ema + 0.25 * done;
         k += done;
     }
     c->batch_ema = ema;
     return check_status(c);
+}
+
+extern "C" int pwr_realign_rows(pwr_ctx *c, int k0, int n)
+{
+    if (!c || k0 < 0 || n < 0 || k0 > c->T || n > c->T - k0) return PWR_ERR_ARG;
+    int rc = ensure_device(c);
+    if (rc) return rc;
+    if (n == 0) return PWR_OK;
+    return realign_range(c, k0, n);
+}
+
+extern "C" int pwr_realign_round(pwr_ctx *c)
+{
+    if (!c) return PWR_ERR_ARG;
+    int rc = ensure_device(c);
+    if (rc) return rc;
+    return realign_range(c, 0, c->T);                                          // PW:1695: rows in input order
 }
 
 extern "C" int pwr_total_score(pwr_ctx *c, uint64_t *total)
@@ -3187,6 +3204,20 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
         return PWR_OK;
     }
     return PWR_ERR_ARG;
+}
+
+extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
+{
+    if (!c || !key || !value) return PWR_ERR_ARG;
+    if (!strcmp(key, "window")) *value = c->window;
+    else if (!strcmp(key, "profile")) *value = c->profile;
+    else if (!strcmp(key, "fill")) *value = c->fill_mode;
+    else if (!strcmp(key, "ptrace")) *value = c->par_trace;
+    else if (!strcmp(key, "slack")) *value = c->cap_slack;
+    else if (!strcmp(key, "waves")) *value = c->wp_waves;
+    else if (!strcmp(key, "threads")) *value = c->threads;
+    else return PWR_ERR_ARG;
+    return PWR_OK;
 }
 
 extern "C" int pwr_get_stats(pwr_ctx *c, pwr_stats *out)

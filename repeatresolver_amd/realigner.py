@@ -4,7 +4,6 @@ The reference has no Python API; its interface is `./PW_ReAligner <MSA> [-o out]
 (PW_ReAligner.c:1610-1647) and, inside, the functions this class names its methods after.
 All work happens in libpwr.so (HIP); nothing here computes."""
 import ctypes
-import io
 import os
 import subprocess
 
@@ -51,6 +50,11 @@ class PWReAligner:
         """pwr_set_option (include/pwr.h); most knobs must be set before the first call that touches the device."""
         _check(self._lib.pwr_set_option(self._h, key.encode(), int(value)), "set " + key)
 
+    def get_option(self, key):
+        v = ctypes.c_long()
+        _check(self._lib.pwr_get_option(self._h, key.encode(), ctypes.byref(v)), "get " + key)
+        return v.value
+
     @classmethod
     def from_file(cls, path, **kw):
         with open(path, "rb") as f:
@@ -79,6 +83,9 @@ class PWReAligner:
 
     def realign_round(self):                 # PW_ReAligner.c:1695-1737
         _check(self._lib.pwr_realign_round(self._h), "pwr_realign_round")
+
+    def realign_rows(self, k0, n):          # rows k0..k0+n-1 of that loop (a slab of PW_ReAligner.c:1695)
+        _check(self._lib.pwr_realign_rows(self._h, k0, n), "pwr_realign_rows")
 
     def total_score(self) -> int:            # OverallScorePrint, PW_ReAligner.c:933-963
         v = ctypes.c_uint64()
@@ -121,42 +128,6 @@ class PWReAligner:
         mhz, us = ctypes.c_double(), ctypes.c_double()
         _check(self._lib.pwr_debug_fill_clock(self._h, ctypes.byref(mhz), ctypes.byref(us)), "pwr_debug_fill_clock")
         return mhz.value, us.value
-
-    # ---- the whole program, PW_ReAligner.c:1610-1759 ----
-    def run(self, out_path, max_rounds=-1, log=None):
-        """Round loop of main(): returns the list of totals printed; writes out_path after every
-        improving round."""
-        def score_line(total):
-            m, u = (0, 0) if total == 0 else ((total - 1) // 1000000, (total - 1) % 1000000 + 1)
-            return "OverallScore: %d%06d" % (m, u)
-        lines = []
-
-        def emit(s):
-            lines.append(s)
-            if log is not None:
-                print(s, file=log, flush=True)
-        self.trim_ends()
-        t, w = self.dims()
-        emit("Rows %d, Columns %d." % (t, w))
-        best = self.total_score()
-        emit(score_line(best))
-        rounds = 0
-        while rounds < 10000 and (max_rounds < 0 or rounds < max_rounds):
-            self.realign_round()
-            rounds += 1
-            tot = self.total_score()
-            emit(score_line(tot))
-            if tot < best:
-                best = tot
-                write_msa(out_path, self.export_rows())
-            else:
-                break
-        self.trim_ends()
-        tot = self.total_score()
-        emit(score_line(tot))
-        if tot < best:
-            write_msa(out_path, self.export_rows())
-        return lines
 
 
 def write_msa(path, rows):
