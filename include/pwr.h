@@ -84,13 +84,11 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
 
 /* Knobs and counters (ours). keys: "window" (max rows filled speculatively per batch, 1..128),
  * "profile" (1 = time every fill launch with HIP events), "fill" (DP fill kernel: 4 = k_fill_v3, the default: one
- * work-group per pipeline wave; 3 = k_fill_v2: one work-group per DP; 1 = k_fill_wp; 0 = k_fill),
- * "waves" (waves per DP of the wave-pipeline fills: 9 (default), 8, 5, 4, 3, or 17 with k_fill_v3 only; bandwidths above
- * 1000 always use 9),
- * "ptrace" (1 = speculative-parallel traceback k_trace_par, the default; 0 = one wave per job),
- * "threads" (work-group size of k_fill: 64, 128, 256, 512 or 1024), "slack" (spare column capacity kept when
- * the device arrays are (re)allocated).  "fill", "waves", "threads" and "slack" must be set before the first call
- * that touches the device. */
+ * work-group per pipeline wave; 3 = k_fill_v2: one work-group per DP, the independent cross-check and fallback, see
+ * DESIGN.md 3.2), "waves" (waves per DP of the wave-pipeline fills: 9 (default), 8, 5, 4, 3, or 17 with k_fill_v3 only;
+ * bandwidths above 1000 always use 9), "ptrace" (1 = speculative-parallel traceback k_trace_par, the default; 0 = one
+ * wave per job), "slack" (spare column capacity kept when the device arrays are (re)allocated).  "fill", "waves" and
+ * "slack" must be set before the first call that touches the device. */
 int pwr_set_option(pwr_ctx *ctx, const char *key, long value);
 int pwr_get_option(pwr_ctx *ctx, const char *key, long *value);
 int pwr_get_stats(pwr_ctx *ctx, pwr_stats *out);

@@ -99,7 +99,6 @@ struct JobBufs {
     unsigned long long *gtr;       // [njobs][TRK]    k_trace_par: hand-over words of the chunks
     unsigned trace_tag;            // 22-bit launch tag of those words
     int njobs_launched;
-    int layout;                    // 0: dirs indexed by band cell (y - anf(x)); 1: by (y - lo) mod NC
     int Lmax, colcap, NC;
     size_t dirstride;
 };
@@ -344,553 +343,6 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// fill: the banded DP of PW:1493-1513 for one row per work-group.
-//
-// Thread t owns band cells j = t*C .. t*C+C-1 of every DP row x (column y = anf(x) + j).
-// The dependency on the left neighbour, M(x,y) = min(t(y), M(x,y-1) + S(y,4)), is a min-plus
-// scan:  M(x,y) = G(y) + min_{j<=y} (t(j) - G(j))  with  t = min(diag, up)  and G the prefix sum of
-// S(.,4); it is evaluated with one DPP wave scan per row plus one LDS exchange between waves.
-// The same formula yields the virtual right extension of PW:285-295 for columns past the band.
-// Previous-row values travel through an LDS ring indexed by absolute column; the column records
-// are staged in a second LDS ring, NC columns at a time.
-// Output: 2 bits per cell -- A: "M == M(x,y-1)+S(y,4)" (PW:1375; on the last row also PW:1386),
-// C: "diag <= up" -- which is all the traceback's ordered equality tests need, and the entry
-// column of PW:1352-1360.
-// ---------------------------------------------------------------------------------------------
-template <int NT, int C>
-__global__ __launch_bounds__(NT) void k_fill(DState st, JobBufs jb)
-{
-    constexpr int NC = NT * C, RC = 4 * NC, RCM = RC - 1, MC = 2 * NC, MCM = MC - 1, NW = NT / 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4 *ring = reinterpret_cast<uint4 *>(smem);
-    unsigned *mring = reinterpret_cast<unsigned *>(smem + (size_t)RC * 16);
-    int *wtot = reinterpret_cast<int *>(mring + MC);
-    unsigned *red = reinterpret_cast<unsigned *>(wtot + 16);
-
-    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    JobMeta *m = &jb.meta[job];
-    const int L = m->L;
-    if (L <= 0 || !m->ok) return;
-    const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
-    const int lo = m->lo, hi = m->hi, W = m->W, B = st.B, H = st.H;
-    const int *way = jb.way + (size_t)job * jb.Lmax;
-    const uint8_t *seq = st.seq + st.rowoff[m->k];
-    const uint4 *rec = jb.rec + (size_t)job * jb.colcap;
-    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
-
-    int loaded_hi = lo;
-    unsigned accA[C], accC[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) accA[i] = accC[i] = 0;
-    unsigned long long cells = 0;
-    // Way[] / Seq_Bases[] of 64 DP rows live in one VGPR each (lane r = row 64*blk + r) and are read
-    // with v_readlane; the next block is fetched one block ahead, so no memory latency per row.
-    int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
-    int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
-    int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H);
-
-    for (int x = 0; x < L; ++x) {
-        if ((x & 63) == 0 && x > 0) {
-            wcur = wnxt; scur = snxt;
-            wnxt = way[min(x + 64 + lane, L - 1)];
-            snxt = seq[min(x + 64 + lane, L - 1)];
-        }
-        const int wn = ((x + 1) & 63) ? __builtin_amdgcn_readlane(wcur, (x + 1) & 63) : __builtin_amdgcn_readlane(wnxt, 0);
-        const int a_next = (x + 1 < L) ? max(0, wn - H) : a;
-        const int wx = __builtin_amdgcn_readlane(wcur, x & 63);
-        const int Bx = min(B, W - a);
-        const int sx = __builtin_amdgcn_readlane(scur, x & 63);
-        // ---- stage column records: keep [a-1, a+B+NC) resident
-        {
-            const int need_hi = min(hi + 1, a + B + NC);
-            if (loaded_hi < need_hi) {
-                if (loaded_hi < a - 1) loaded_hi = max(lo, a - 1);
-                while (loaded_hi < need_hi) {
-#pragma unroll
-                    for (int i = 0; i < C; ++i) {
-                        const int y = loaded_hi + i * NT + tid;
-                        if (y <= hi) ring[y & RCM] = rec[y - lo];
-                    }
-                    loaded_hi += NC;
-                }
-                __syncthreads();
-            }
-        }
-        const unsigned Gb = ring[a & RCM].z;
-        // ---- candidates from the previous DP row
-        int tg[C], grel[C];
-        bool fc[C];
-        int run = PWR_BIG;
-#pragma unroll
-        for (int i = 0; i < C; ++i) {
-            const int j = tid * C + i;
-            const int y = a + j;
-            const uint4 r = ring[y & RCM];
-            grel[i] = (int)(r.z - Gb);
-            unsigned pm = 0, pm1 = 0;                       // x == 0: MatrixOut(-1, .) = 0 (PW:256)
-            if (x > 0) { pm = mring[y & MCM]; pm1 = mring[(y - 1) & MCM]; }
-            const unsigned sy = (((sx & 2) ? r.y : r.x) >> ((sx & 1) * 16)) & 0xffffu;
-            const unsigned diag = pm1 + sy;                 // PW:1503
-            const unsigned up = pm + r.w;                   // PW:1507 (r.w = INF where PW:1505 forbids)
-            const unsigned t = min(min(diag, up), PWR_INF);
-            fc[i] = diag <= up;
-            tg[i] = (j < Bx) ? (int)t - grel[i] : PWR_BIG;
-            run = min(run, tg[i]);
-        }
-        // ---- min-plus scan across the band
-        const int incl = wave_incl_min(run);
-        const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
-        if (lane == 63) wtot[wave] = incl;
-        __syncthreads();                                    // B1: also orders all mring reads before the writes below
-        int wv = (lane < NW) ? wtot[lane] : PWR_BIG;
-        wv = row_incl_min(wv);
-        const int ptot = __builtin_amdgcn_readlane(wv, NW - 1);
-        const int xw = (wave == 0) ? PWR_BIG : __builtin_amdgcn_readlane(wv, wave > 0 ? wave - 1 : 0);
-        int p = min(xw, excl);
-        // ---- finish cells, record traceback bits, publish the row for x+1
-        int Mv[C];
-#pragma unroll
-        for (int i = 0; i < C; ++i) {
-            const int j = tid * C + i;
-            const int y = a + j;
-            bool fa = tg[i] >= p;                           // prefix minimum did not drop: M == left + S(y,4)
-            const int pex = p;
-            p = min(p, tg[i]);
-            const int M = grel[i] + p;
-            Mv[i] = M;
-            if (x == L - 1 && j > 0) {                      // PW:1386: on the last row "M == left" also moves left
-                const int gl = (int)(ring[(y - 1) & RCM].z - Gb);
-                fa = fa || (M == gl + pex);
-            }
-            accA[i] = (accA[i] << 1) | (fa ? 1u : 0u);
-            accC[i] = (accC[i] << 1) | (fc[i] ? 1u : 0u);
-            if (j < Bx && y >= a_next - 1) mring[y & MCM] = (unsigned)M;
-        }
-        if (x + 1 < L) {
-            // virtual extension (PW:285-295) for the columns row x+1 reads beyond this band
-            const int wr_end = a_next + min(B, W - a_next);
-            for (int y = a + Bx + tid; y < wr_end; y += NT) {
-                if (y >= a_next - 1) {
-                    const unsigned g = (y < loaded_hi) ? ring[y & RCM].z : rec[y - lo].z;
-                    mring[y & MCM] = (unsigned)((int)(g - Gb) + ptot);
-                }
-            }
-            if (tid == 0 && a_next == a) mring[(a - 1) & MCM] = PWR_INF;   // PW:276: left of the band
-        } else {
-            // ---- entry column, PW:1352-1360: minimum over y in [ylow, W-1], ties -> largest y;
-            // every column past the band has the value of the last band cell (PW:287)
-            int ylow = max(-1, wx - H) + 1;
-            if (ylow > W - 1) ylow = W - 1;
-            unsigned key = 0xffffffffu;
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                const int j = tid * C + i;
-                if (j < Bx && a + j >= ylow) key = min(key, (unsigned)Mv[i]);
-            }
-            const unsigned vmin = block_min_u32<NT>(key, red);
-            int cand = -1;
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                const int j = tid * C + i;
-                if (j < Bx && a + j >= ylow && (unsigned)Mv[i] == vmin) cand = a + j;
-            }
-            const int ybest = block_max_i32<NT>(cand, reinterpret_cast<int *>(red));
-            const bool beyond = (a + B <= W - 1);
-#pragma unroll
-            for (int i = 0; i < C; ++i)
-                if (tid * C + i == B - 1) red[0] = (unsigned)Mv[i];
-            __syncthreads();
-            if (tid == 0) {
-                int entry = ybest;
-                if (beyond && red[0] <= vmin) entry = W - 1;
-                m->entry = entry;
-            }
-        }
-        cells += (unsigned long long)Bx;
-        if ((x & 15) == 15 || x == L - 1) {
-            const int sh = 15 - (x & 15);
-            uint32_t *d = dirs + (size_t)(x >> 4) * NC + (size_t)tid * C;
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                d[i] = ((accA[i] << sh) & 0xffffu) | (((accC[i] << sh) & 0xffffu) << 16);
-                accA[i] = accC[i] = 0;
-            }
-        }
-        __syncthreads();                                    // B2: row x published
-        a = a_next;
-    }
-    if (tid == 0) {
-        m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
-        m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
-        atomicAdd(&st.hdr->cells_computed, m->cells);
-        (void)cells;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// trace: Backtracker (PW:1334-1454), one wave per job.  For DP row x at column y the ordered tests
-// (a)/(b) "left", (c) "diag", (d) "up" reduce to: walk left while bit A is set (cells past the band
-// are always "left", PW:285-295), then C decides between placing the base in column y (diag) and
-// opening a new column after y (up).  The wave looks at 256 cells of one 16-row group at a time.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_trace(DState st, JobBufs jb)
-{
-    const int job = blockIdx.x, lane = threadIdx.x;
-    JobMeta *m = &jb.meta[job];
-    const int L = m->L;
-    if (L <= 0 || !m->ok) return;
-    const int W = m->W, B = st.B, H = st.H, NC = jb.NC;
-    const int *way = jb.way + (size_t)job * jb.Lmax;
-    const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
-    int *newcol = jb.newcol + (size_t)job * jb.Lmax;
-
-    int x = L - 1, y = m->entry, err = 0, nnew = 0;
-    int gcur = -1, jb0 = 0;
-    uint32_t win[4] = {0, 0, 0, 0};
-    int gpre = -1, jbpre = 0;
-    uint32_t pre[4] = {0, 0, 0, 0};
-    // Way[] of the current 64-row block in one VGPR (lane r = row 64*blk + r), next block prefetched;
-    // the new placements of a block are collected in a VGPR and stored 64 at a time.
-    int blk = x >> 6;
-    int wcur = way[min(blk * 64 + lane, L - 1)];
-    int wnxt = way[max(blk * 64 - 64 + lane, 0)];
-    int ncreg = 0;
-    while (x >= 0) {
-        if ((x >> 6) != blk) {
-            if (blk * 64 + lane < L) newcol[blk * 64 + lane] = ncreg;   // block complete
-            blk = x >> 6;
-            wcur = wnxt;
-            wnxt = way[max(blk * 64 - 64 + lane, 0)];
-        }
-        const int a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
-        const int Bx = min(B, W - a);
-        if (y < a) { err = 1; break; }                       // left of the band: unreachable (PW:276)
-        int j = min(y - a, Bx - 1);                          // past the band: implicit left moves
-        const int g = x >> 4, sh = 15 - (x & 15);
-        int found = -1, cbit = 0;
-        for (;;) {
-            if (g != gcur || j < jb0 || j > jb0 + 255) {
-                const int want = max(0, min(j - 191, NC - 256));
-                if (gpre == g && jbpre == want) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) win[q] = pre[q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) win[q] = dirs[(size_t)g * NC + want + 64 * q + lane];
-                }
-                gcur = g; jb0 = want;
-                if (g > 0) {                                 // prefetch the same window of the next group
-                    gpre = g - 1; jbpre = want;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) pre[q] = dirs[(size_t)(g - 1) * NC + want + 64 * q + lane];
-                }
-            }
-#pragma unroll
-            for (int q = 3; q >= 0; --q) {
-                if (found < 0) {
-                    const int cell = jb0 + 64 * q + lane;
-                    const bool abit = (win[q] >> sh) & 1u;
-                    const unsigned long long mk = __ballot(cell <= j && !abit);
-                    if (mk) {
-                        const int t = 63 - __builtin_clzll(mk);
-                        found = jb0 + 64 * q + t;
-                        const unsigned long long ck = __ballot((win[q] >> (16 + sh)) & 1u);
-                        cbit = (int)((ck >> t) & 1ull);
-                    }
-                }
-            }
-            if (found >= 0) break;
-            if (jb0 == 0) { err = 2; break; }
-            j = jb0 - 1;
-        }
-        if (err) break;
-        const int yy = a + found;
-        if (cbit) { ncreg = (lane == (x & 63)) ? (yy << 1) : ncreg; y = yy - 1; }            // PW:1394 (c)
-        else { ncreg = (lane == (x & 63)) ? ((yy << 1) | 1) : ncreg; y = yy; ++nnew; }       // PW:1404 (d)
-        --x;
-        if (x >= 0 && y < 0) { err = 3; break; }
-    }
-    if (!err && blk * 64 + lane < L) newcol[blk * 64 + lane] = ncreg;
-    if (lane == 0) {
-        m->nnew = nnew;
-        if (err) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// fill, wave-pipeline form.  Same recurrence and same min-plus scan as k_fill, but nothing is
-// staged through LDS rows and there is no work-group barrier per DP row:
-//   * columns are owned absolutely: macro-strip ms = 64*C consecutive columns belongs to wave
-//     ms mod NW, lane l holds C of them IN REGISTERS (records, and the previous DP row's scores);
-//     NW*64*C >= B + 64*C, so a wave never has two macro-strips inside one band;
-//   * inside a wave the scan is one DPP prefix-min; between waves the running minimum and the
-//     boundary score travel through small LDS mailboxes {value, tag = row+1} written with one
-//     64-bit store, so wave w works on row x while its right neighbour is still on an earlier row;
-//   * a wave whose macro-strip dropped out of the band on the left takes over the macro-strip NW
-//     further right; its records were fetched long before, its previous-row scores are the virtual
-//     extension G(y) + Ptot of PW:285-295.
-// Every wait is bounded; on a time-out the job is flagged and all waves leave.
-// ---------------------------------------------------------------------------------------------
-#define MB_D 32
-#define PT_D 512
-#define WP_SPIN_LIMIT (1 << 22)
-
-// wait until the 64-bit mailbox word SLOT (an lvalue in LDS) carries TAG in its upper half; bounded
-#define WP_WAIT(SLOT, TAG, VAL, OK)                                                              \
-    do {                                                                                         \
-        (OK) = false;                                                                            \
-        for (int spin_ = 0; spin_ < WP_SPIN_LIMIT; ++spin_) {                                    \
-            const unsigned long long v_ = __hip_atomic_load(&(SLOT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-            const unsigned vhi_ = __builtin_amdgcn_readfirstlane((unsigned)(v_ >> 32));              \
-            const unsigned vlo_ = __builtin_amdgcn_readfirstlane((unsigned)v_);                      \
-            if (vhi_ == (unsigned)(TAG)) { (VAL) = vlo_; (OK) = true; break; }                       \
-            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break; \
-            __builtin_amdgcn_s_sleep(1);                                                         \
-        }                                                                                        \
-        if (!(OK)) __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-    } while (0)
-
-template <int NW, int C>
-__global__ __launch_bounds__(NW * 64) void k_fill_wp(DState st, JobBufs jb)
-{
-    constexpr int MS = 64 * C, RS = NW * MS;
-    __shared__ unsigned long long mbP[NW][MB_D], mbM[NW][MB_D], ptb[PT_D];
-    __shared__ int prog[NW];
-    __shared__ int s_abort;
-
-    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    JobMeta *m = &jb.meta[job];
-    const int L = m->L;
-    if (L <= 0 || !m->ok) return;
-    const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
-    for (int i = tid; i < NW * MB_D; i += NW * 64) { (&mbP[0][0])[i] = 0; (&mbM[0][0])[i] = 0; }
-    for (int i = tid; i < PT_D; i += NW * 64) ptb[i] = 0;
-    if (tid < NW) prog[tid] = 0;
-    if (tid == 0) s_abort = 0;
-    __syncthreads();                                        // the only work-group barrier
-
-    const int lo = m->lo, hi = m->hi, W = m->W, B = st.B, H = st.H;
-    const int *way = jb.way + (size_t)job * jb.Lmax;
-    const unsigned *gbase = jb.gbase + (size_t)job * jb.Lmax;
-    const uint8_t *seq = st.seq + st.rowoff[m->k];
-    const uint4 *rec = jb.rec + (size_t)job * jb.colcap;
-    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
-    unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
-    const int wl = (wave + NW - 1) % NW, wr = (wave + 1) % NW;
-
-    // records of the wave's macro-strip: x = S0|S1<<16, y = S2|S3<<16, z = G, w = up cost
-    uint4 r[C], rn[C];
-    unsigned gleft = 0, gleftn = 0;
-    int ms = wave, msn = wave + NW;
-#pragma unroll
-    for (int i = 0; i < C; ++i) {
-        const int y = lo + ms * MS + lane * C + i;
-        r[i] = make_uint4(0, 0, 0, PWR_INF);
-        if (y <= hi) r[i] = rec[y - lo];
-        const int yn = lo + msn * MS + lane * C + i;
-        rn[i] = make_uint4(0, 0, 0, PWR_INF);
-        if (yn <= hi) rn[i] = rec[yn - lo];
-    }
-    { const int yq = lo + ms * MS - 1; gleft = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
-    { const int yq = lo + msn * MS - 1; gleftn = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
-
-    unsigned Mprev[C];
-    unsigned accA[C], accC[C];
-#pragma unroll
-    for (int i = 0; i < C; ++i) { Mprev[i] = 0; accA[i] = accC[i] = 0; }
-    bool ran_prev = false;
-    int cons_known = 0;
-    unsigned long long cells = 0;
-
-    int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
-    unsigned gcur = gbase[min(lane, L - 1)];
-    int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
-    unsigned gnxt = gbase[min(64 + lane, L - 1)];
-    int a_prev = 0, Bx_prev = 0;
-    unsigned gb_prev = 0;
-    bool dead = false;
-
-    for (int x = 0; x < L && !dead; ++x) {
-        if ((x & 63) == 0 && x > 0) {
-            wcur = wnxt; scur = snxt; gcur = gnxt;
-            wnxt = way[min(x + 64 + lane, L - 1)];
-            snxt = seq[min(x + 64 + lane, L - 1)];
-            gnxt = gbase[min(x + 64 + lane, L - 1)];
-        }
-        const int wx = __builtin_amdgcn_readlane(wcur, x & 63);
-        const int sx = __builtin_amdgcn_readlane(scur, x & 63);
-        const unsigned gb = (unsigned)__builtin_amdgcn_readlane((int)gcur, x & 63);
-        const int a = max(0, wx - H);
-        const int Bx = min(B, W - a);
-        const int ms_lo = (a - lo) / MS, ms_hi = (a + Bx - 1 - lo) / MS;
-        if (wave == 0) cells += (unsigned long long)Bx;
-        // ---- the macro-strip left the band for good: take over the one NW further right
-        while (ms < ms_lo) {
-            ms += NW;
-            if (ms == msn) {
-#pragma unroll
-                for (int i = 0; i < C; ++i) r[i] = rn[i];
-                gleft = gleftn;
-            } else {                                        // a jump skipped whole macro-strips (rare)
-                while (ms < ms_lo) ms += NW;
-#pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    const int y = lo + ms * MS + lane * C + i;
-                    r[i] = make_uint4(0, 0, 0, PWR_INF);
-                    if (y <= hi) r[i] = rec[y - lo];
-                }
-                const int yq = lo + ms * MS - 1;
-                gleft = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u;
-            }
-            msn = ms + NW;
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                const int yn = lo + msn * MS + lane * C + i;
-                rn[i] = make_uint4(0, 0, 0, PWR_INF);
-                if (yn <= hi) rn[i] = rec[yn - lo];
-            }
-            { const int yq = lo + msn * MS - 1; gleftn = (yq >= lo && yq <= hi) ? rec[yq - lo].z : 0u; }
-            ran_prev = false;
-        }
-        const bool task = ms <= ms_hi;
-        bool fcv[C], fav[C];
-#pragma unroll
-        for (int i = 0; i < C; ++i) { fcv[i] = false; fav[i] = false; }
-        if (task) {
-            const int y0 = lo + ms * MS;
-            const int yl = y0 + lane * C;
-            // ---- inputs from the left neighbour / from the row before
-            unsigned Mleft = PWR_INF;
-            int P_in = PWR_BIG;
-            bool ok = true;
-            unsigned pt_prev = 0;
-            bool have_pt = false;
-            if (x == 0) {
-                Mleft = 0;
-            } else {
-                const int yq = y0 - 1;
-                if (yq < a_prev) Mleft = PWR_INF;                                    // PW:276
-                else if (yq < a_prev + Bx_prev) WP_WAIT(mbM[wl][(x - 1) & (MB_D - 1)], x, Mleft, ok);
-                else {                                                               // PW:285-295
-                    WP_WAIT(ptb[(x - 1) & (PT_D - 1)], x, pt_prev, ok);
-                    have_pt = true;
-                    Mleft = (gleft - gb_prev) + pt_prev;
-                }
-                if (ok && !ran_prev) {
-                    if (!have_pt) WP_WAIT(ptb[(x - 1) & (PT_D - 1)], x, pt_prev, ok);
-#pragma unroll
-                    for (int i = 0; i < C; ++i) Mprev[i] = (r[i].z - gb_prev) + pt_prev;
-                }
-            }
-            if (ok && ms > ms_lo) {
-                unsigned v = 0;
-                WP_WAIT(mbP[wl][x & (MB_D - 1)], x + 1, v, ok);
-                P_in = (int)v;
-            }
-            if (!ok) { dead = true; break; }
-            // ---- candidates
-            const unsigned pm1_0 = (unsigned)__builtin_amdgcn_update_dpp((int)Mleft, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
-            int tg[C], grel[C];
-            bool inb[C], lft[C];
-            int run = PWR_BIG;
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                const int rel = yl + i - a;
-                inb[i] = (unsigned)rel < (unsigned)Bx;
-                lft[i] = rel < 0;
-                grel[i] = (int)(r[i].z - gb);
-                const unsigned pm = Mprev[i];
-                const unsigned pm1 = i ? Mprev[i > 0 ? i - 1 : 0] : pm1_0;
-                const unsigned sy = (((sx & 2) ? r[i].y : r[i].x) >> ((sx & 1) * 16)) & 0xffffu;
-                const unsigned diag = pm1 + sy;                                      // PW:1503
-                const unsigned up = pm + r[i].w;                                     // PW:1507
-                const unsigned t = min(min(diag, up), PWR_INF);
-                fcv[i] = diag <= up;
-                tg[i] = inb[i] ? (int)t - grel[i] : PWR_BIG;
-                run = min(run, tg[i]);
-            }
-            const int incl = wave_incl_min(run);
-            const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
-            const int P_end = min(P_in, __builtin_amdgcn_readlane(incl, 63));
-            int p = min(P_in, excl);
-            unsigned Mn[C];
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                fav[i] = tg[i] >= p;
-                p = min(p, tg[i]);
-                Mn[i] = lft[i] ? PWR_INF : (unsigned)(grel[i] + p);
-            }
-            if (x == L - 1) {
-                // PW:1386: on the last row "M == M(x,y-1)" also moves left; keep the row for the entry scan
-                unsigned mrow = PWR_INF;
-                if (ms > ms_lo) { bool ok2; WP_WAIT(mbM[wl][x & (MB_D - 1)], x + 1, mrow, ok2); if (!ok2) { dead = true; break; } }
-                const unsigned left0 = (unsigned)__builtin_amdgcn_update_dpp((int)mrow, (int)Mn[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
-#pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    const unsigned lf = i ? Mn[i > 0 ? i - 1 : 0] : left0;
-                    fav[i] = fav[i] || (inb[i] && Mn[i] == lf);
-                    lastM[wave * MS + lane * C + i] = inb[i] ? Mn[i] : 0xffffffffu;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < C; ++i) Mprev[i] = Mn[i];
-            // ---- publish for the right neighbour (and the row minimum for late joiners)
-            const int need = x - MB_D + 2;
-            if (need > cons_known) {
-                int v = 0, spin = 0;
-                for (; spin < WP_SPIN_LIMIT; ++spin) {
-                    v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&prog[wr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                    if (v >= need || __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (spin == WP_SPIN_LIMIT) __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) { dead = true; break; }
-                cons_known = v;
-            }
-            if (lane == 63) {
-                const unsigned long long tag = (unsigned long long)(unsigned)(x + 1) << 32;
-                __hip_atomic_store(&mbM[wave][x & (MB_D - 1)], tag | (unsigned long long)Mn[C - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_store(&mbP[wave][x & (MB_D - 1)], tag | (unsigned long long)(unsigned)P_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (ms == ms_hi) __hip_atomic_store(&ptb[x & (PT_D - 1)], tag | (unsigned long long)(unsigned)P_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            ran_prev = true;
-        } else {
-            ran_prev = false;
-        }
-#pragma unroll
-        for (int i = 0; i < C; ++i) {
-            accA[i] = (accA[i] << 1) | (fav[i] ? 1u : 0u);
-            accC[i] = (accC[i] << 1) | (fcv[i] ? 1u : 0u);
-        }
-        if ((x & 15) == 15 || x == L - 1) {
-            const int sh = 15 - (x & 15);
-            uint32_t *d = dirs + (size_t)(x >> 4) * RS + (size_t)wave * MS + (size_t)lane * C;
-#pragma unroll
-            for (int i = 0; i < C; ++i) {
-                d[i] = ((accA[i] << sh) & 0xffffu) | (((accC[i] << sh) & 0xffffu) << 16);
-                accA[i] = accC[i] = 0;
-            }
-        }
-        if (lane == 0) __hip_atomic_store(&prog[wave], x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        a_prev = a; Bx_prev = Bx; gb_prev = gb;
-    }
-    if (dead || __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-        if (lane == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
-        return;
-    }
-    if (tid == 0) {
-        m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
-        m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
-        atomicAdd(&st.hdr->cells_computed, m->cells);
-        (void)cells;
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
 // fill v2: the wave pipeline in lock-step rounds (one s_barrier per round instead of polled mailboxes),
 // with the per-cell and per-row work cut down.
 //   * prefix sums G are absolute (their total is the number of bases in the interval, < 2^29, checked by
@@ -935,20 +387,9 @@ __device__ __forceinline__ unsigned acc_push(unsigned acc, unsigned long long ma
         GL = (yq_ >= lo && yq_ <= hi) ? UNI(rec2[2 * (yq_ - lo) + 1].y) : 0;                     \
     }
 
-#ifdef PWR_STAMPS
-#define ST_NOW() __builtin_amdgcn_s_memtime()
-#define ST_DECL unsigned long long st_gwait = 0, st_nowork = 0, st_gw0 = 0, st_fast = 0, st_spin = 0, st_gen = 0, st_bar = 0, st_load = 0, st_t = 0, st_rows = 0, st_entries = 0, st_spins = 0, st_grows = 0;
-#define ST_BEGIN() st_t = ST_NOW();
-#define ST_END(ACC) ACC += ST_NOW() - st_t;
-#else
-#define ST_DECL
-#define ST_BEGIN()
-#define ST_END(ACC)
-#endif
 template <int NW, int C>
 __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 {
-    ST_DECL
     constexpr int MS = 64 * C, RS = NW * MS;
     // What lane 63 of a wave publishes per DP row.  Every item is one 64-bit word {value, row + 1}, stored and loaded
     // with single 8-byte LDS accesses (relaxed atomics, so the compiler can neither split nor merge them): the row
@@ -1091,9 +532,6 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 asm volatile("" : "+v"(mlast_v));
                 int cnt = min(budget, xstop - x) - 1;                                // rows the loop may still take, less one
                 int bail = 0;
-#ifdef PWR_STAMPS
-                ++st_entries; const unsigned long long st_f0 = ST_NOW(); unsigned long long st_sp = 0;
-#endif
                 // One ordinary row.  fl = its flags, dbn = the {Bx, base} descriptor word of the row after it.
                 auto fast_row = [&](const int fl, const unsigned dbn) __attribute__((always_inline)) {
                     const int af = (int)(db & 0xffffffu);
@@ -1155,18 +593,12 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                         if (!V2_BOTH_THERE()) {
                             // bounded; gives up at once when the neighbour has left the round (rdone is stored after its
                             // last entry, and LDS keeps one wave's stores in order)
-#ifdef PWR_STAMPS
-                            const unsigned long long st_s0 = ST_NOW(); ++st_spins;
-#endif
                             for (int spin = 0; spin < V2_SPINS; ++spin) {
                                 const int rd = UNI(__hip_atomic_load(&rdone[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                                 __builtin_amdgcn_s_sleep(1);
                                 fM = LD64(MBM(wl, x)); fP = LD32LO(MBP(wl, x));
                                 if (V2_BOTH_THERE() || rd == round + 1) break;
                             }
-#ifdef PWR_STAMPS
-                            st_sp += ST_NOW() - st_s0;
-#endif
                             if (!V2_BOTH_THERE()) bail = 1;
                         }
 #undef V2_BOTH_THERE
@@ -1222,9 +654,6 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                         }
                     }
                 }
-#ifdef PWR_STAMPS
-                st_fast += ST_NOW() - st_f0 - st_sp; st_spin += st_sp; st_rows += x - x_in;
-#endif
                 budget -= x - x_in;
                 if (bail) {                                      // take the unfinished row back and leave the round
 #pragma unroll
@@ -1239,10 +668,6 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 }
             }
             if (not_ready || budget <= 0) break;
-            ST_BEGIN()
-#ifdef PWR_STAMPS
-            ++st_grows;
-#endif
             x = UNI(x); ms = UNI(ms); msn = UNI(msn); a = UNI(a); a_prev = UNI(a_prev); Bx_prev = UNI(Bx_prev);
             sx = UNI(sx); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); gleft = UNI(gleft); gleftn = UNI(gleftn); ran_prev = UNI(ran_prev); cs = UNI(cs);
             const int Bx = min(B, W - a);
@@ -1262,16 +687,11 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                 msn = ms + NW;
                 V2_LOAD(msn, cs ^ 1, nu, ng, ni, gleftn)
                 ran_prev = 0;
-                ST_END(st_load)
                 continue;
             }
             if (ms > ms_hi) {                               // no work for this wave in row x
                 ran_prev = 0;
                 V2_NEXT_ROW()
-#ifdef PWR_STAMPS
-                ++st_nowork;
-#endif
-                ST_END(st_gen)
                 continue;
             }
             // ---- inputs of (x, ms): written by the left neighbour before the last barrier?
@@ -1284,9 +704,6 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
             // has left the round (rdone is stored after its last entry, LDS keeps one wave's stores in order)
             unsigned ePx = 0, ePy = 0, eMy = 0, eTx = 0;
             bool ready = false;
-#ifdef PWR_STAMPS
-            st_gw0 = ST_NOW();
-#endif
             for (int spin = 0; spin < V2_SPINS; ++spin) {
                 const int rd = UNI(__hip_atomic_load(&rdone[wl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (spin) __builtin_amdgcn_s_sleep(1);
@@ -1299,10 +716,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
                         (!needM || UNI((unsigned)(eM >> 32)) == (unsigned)x) && (!needT || UNI((unsigned)(eT >> 32)) == (unsigned)x);
                 if (ready || rd == round + 1) break;
             }
-#ifdef PWR_STAMPS
-            st_gwait += ST_NOW() - st_gw0;
-#endif
-            if (!ready) { ST_END(st_gen) break; }
+            if (!ready) break;
             --budget;
             int Mleft = (int)PWR_INF;
             if (x == 0) Mleft = 0;
@@ -1371,21 +785,15 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
             }
             ran_prev = 1;
             V2_NEXT_ROW()
-            ST_END(st_gen)
         }
-        ST_BEGIN()
         if (lane == 0) __hip_atomic_store(&rdone[wave], round + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
-        ST_END(st_bar)
         if (UNI(__hip_atomic_load(&s_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= NW) break;
     }
     if (round >= max_rounds) {
         if (tid == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
         return;
     }
-#ifdef PWR_STAMPS
-    if (lane == 0) printf("wave%d L %d total %llu fast %llu (rows %llu entries %llu) spin %llu (n %llu) general %llu (n %llu, no-work %llu, waiting %llu) load %llu barrier %llu rounds %d\n", wave, L, (unsigned long long)(ST_NOW() - t_clk0), st_fast, st_rows, st_entries, st_spin, st_spins, st_gen, st_grows, st_nowork, st_gwait, st_load, st_bar, round);
-#endif
     if (tid == 0) {
         m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
         m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
@@ -2525,14 +1933,12 @@ struct pwr_ctx {
     int window = 8;
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
-    int threads = 256;
     int par_trace = 1;                    // 1: speculative-parallel traceback (k_trace_par), 0: single-wave k_trace_wp
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
-    int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP), 1: k_fill_wp, 0: k_fill
+    int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP; cross-check and fallback)
     unsigned trace_epoch = 0;             // k_trace_par launch counter (22 bits)
     unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
     int wp_waves = 9;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane
-    int cells_per_thread = 1;
     // stats
     pwr_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -2672,11 +2078,10 @@ static void host_trim(pwr_ctx *c)
 static int alloc_jobs(pwr_ctx *c, int njobs)
 {
     JobBufs &jb = c->jb;
-    if (c->B > 1000 || (c->fill_mode != 3 && c->fill_mode != 4)) c->wp_waves = 9;
+    if (c->B > 1000) c->wp_waves = 9;
     if (c->wp_waves == 17 && c->fill_mode != 4) c->wp_waves = 9;          // 17 x 64 threads do not fit one work-group
     const int wpC = c->wp_waves == 17 ? 1 : c->wp_waves == 8 ? 3 : c->wp_waves == 5 ? 4 : c->wp_waves == 4 ? 6 : c->wp_waves == 3 ? 8 : (c->B <= 1024 ? 2 : 4);
-    const int NC = c->fill_mode ? c->wp_waves * 64 * wpC : c->threads * c->cells_per_thread;
-    jb.layout = c->fill_mode ? 1 : 0;
+    const int NC = c->wp_waves * 64 * wpC;
     jb.Lmax = std::max(c->Lmax, 1);
     jb.colcap = c->st.colcap;
     jb.NC = NC;
@@ -2693,7 +2098,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     if ((rc = dmalloc(c, &jb.aux, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.gbase, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.desc, (size_t)njobs * jb.Lmax))) return rc;
-    jb.wpNW = (c->fill_mode == 3 || c->fill_mode == 4) ? c->wp_waves : 0;
+    jb.wpNW = c->wp_waves;
     jb.wpMS = 64 * wpC;
     if ((rc = dmalloc(c, &jb.lastM, (size_t)njobs * jb.NC))) return rc;
     if (c->fill_mode == 4) {
@@ -2884,8 +2289,6 @@ static int ensure_capacity(pwr_ctx *c, long long growth)
 
 static int launch_fill(pwr_ctx *c, int njobs)
 {
-    const int NT = c->threads, C = c->cells_per_thread, NC = NT * C;
-    const size_t lds = (size_t)4 * NC * 16 + (size_t)2 * NC * 4 + 16 * 4 + 64 * 4;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool timed = c->profile && c->ev_used < (size_t)(1 << 16);      // beyond that the launches are sampled no further
     if (timed) {
@@ -2924,21 +2327,7 @@ static int launch_fill(pwr_ctx *c, int njobs)
         else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v2<3, 8>), dim3(njobs), dim3(3 * 64), 0, c->stream, c->st, c->jb);
         else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v2<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_v2<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
-    } else if (c->fill_mode == 1) {
-        if (c->B <= 1024) hipLaunchKernelGGL((k_fill_wp<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
-        else hipLaunchKernelGGL((k_fill_wp<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
-    }
-    else if (NT == 1024 && C == 1) hipLaunchKernelGGL((k_fill<1024, 1>), dim3(njobs), dim3(1024), lds, c->stream, c->st, c->jb);
-    else if (NT == 512 && C == 2) hipLaunchKernelGGL((k_fill<512, 2>), dim3(njobs), dim3(512), lds, c->stream, c->st, c->jb);
-    else if (NT == 1024 && C == 2) hipLaunchKernelGGL((k_fill<1024, 2>), dim3(njobs), dim3(1024), lds, c->stream, c->st, c->jb);
-    else if (NT == 256 && C == 4) hipLaunchKernelGGL((k_fill<256, 4>), dim3(njobs), dim3(256), lds, c->stream, c->st, c->jb);
-    else if (NT == 256 && C == 8) hipLaunchKernelGGL((k_fill<256, 8>), dim3(njobs), dim3(256), lds, c->stream, c->st, c->jb);
-    else if (NT == 128 && C == 8) hipLaunchKernelGGL((k_fill<128, 8>), dim3(njobs), dim3(128), lds, c->stream, c->st, c->jb);
-    else if (NT == 128 && C == 16) hipLaunchKernelGGL((k_fill<128, 16>), dim3(njobs), dim3(128), lds, c->stream, c->st, c->jb);
-    else if (NT == 64 && C == 16) hipLaunchKernelGGL((k_fill<64, 16>), dim3(njobs), dim3(64), lds, c->stream, c->st, c->jb);
-    else if (NT == 64 && C == 32) hipLaunchKernelGGL((k_fill<64, 32>), dim3(njobs), dim3(64), lds, c->stream, c->st, c->jb);
-    else if (NT == 512 && C == 4) hipLaunchKernelGGL((k_fill<512, 4>), dim3(njobs), dim3(512), lds, c->stream, c->st, c->jb);
-    else return PWR_ERR_ARG;
+    } else return PWR_ERR_ARG;
     HIPC(hipGetLastError());
     if (timed) { HIPC(hipEventRecord(e1, c->stream)); c->stats.fill_launches_timed += 1; }
     c->stats.fill_launches += 1;
@@ -2958,43 +2347,12 @@ static int drain_events(pwr_ctx *c)
     return PWR_OK;
 }
 
-static int configure_kernels(pwr_ctx *c)
-{
-    static bool done = false;
-    if (done) return PWR_OK;
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<1024, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<1024, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<256, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<128, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<128, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<64, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<64, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill<512, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-    done = true;
-    return PWR_OK;
-}
-
-// choose threads / cells per thread so that the band fits: NT*C >= B
-static int pick_geometry(pwr_ctx *c)
-{
-    const int nc = c->B <= 1024 ? 1024 : 2048;            // band cells per DP row handled by one work-group
-    int nt = c->threads;
-    if (nt != 64 && nt != 128 && nt != 256 && nt != 512 && nt != 1024) nt = 256;
-    if (nc / nt > 32) nt = nc / 32;
-    c->threads = nt;
-    c->cells_per_thread = nc / nt;
-    return PWR_OK;
-}
-
 static int ensure_device(pwr_ctx *c)
 {
     if (c->on_device) { if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE; return PWR_OK; }
-    pick_geometry(c);
     int rc = upload(c);
     if (rc) { free_device(c); return rc; }
-    return configure_kernels(c);
+    return PWR_OK;
 }
 
 static int check_status(pwr_ctx *c)
@@ -3024,13 +2382,12 @@ static int run_batch(pwr_ctx *c, int k0, int n, int *done)
     if (rc) return rc;
     hipLaunchKernelGGL(k_gather, dim3(n), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids + k0);
     if ((rc = launch_fill(c, n))) return rc;
-    if (c->fill_mode && c->par_trace) {
+    if (c->par_trace) {
         if (++c->trace_epoch >= (1u << 22)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * 16 * 8, c->stream)); c->trace_epoch = 1; }
         c->jb.trace_tag = c->trace_epoch;
         hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
     }
-    else if (c->fill_mode) hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
-    else hipLaunchKernelGGL(k_trace, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
+    else hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
     hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n);
     HIPC(hipGetLastError());
     Hdr h;
@@ -3191,18 +2548,13 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     // window beyond what one CU-full of jobs survives is of no use anyway)
     if (!strcmp(key, "window")) { if (value < 1 || value > 128 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
-    if (!strcmp(key, "fill")) { if (c->on_device || (value != 0 && value != 1 && value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
+    if (!strcmp(key, "fill")) { if (c->on_device || (value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "ptrace")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
     if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }
     // (test hooks: where the launch counters behind the mailbox / hand-over tags stand, so that their wrap-around can be exercised)
     if (!strcmp(key, "fill_epoch")) { if (value < 0 || value >= (1 << 15)) return PWR_ERR_ARG; c->fill_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "trace_epoch")) { if (value < 0 || value >= (1 << 22)) return PWR_ERR_ARG; c->trace_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9 && value != 17)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
-    if (!strcmp(key, "threads")) {
-        if (c->on_device || (value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)) return PWR_ERR_ARG;
-        c->threads = (int)value;
-        return PWR_OK;
-    }
     return PWR_ERR_ARG;
 }
 
@@ -3215,7 +2567,6 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "ptrace")) *value = c->par_trace;
     else if (!strcmp(key, "slack")) *value = c->cap_slack;
     else if (!strcmp(key, "waves")) *value = c->wp_waves;
-    else if (!strcmp(key, "threads")) *value = c->threads;
     else return PWR_ERR_ARG;
     return PWR_OK;
 }

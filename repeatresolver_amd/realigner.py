@@ -24,7 +24,7 @@ def _check(code, what):
 class PWReAligner:
     """One MSA resident on one GPU.  rows: list of equal-length bytes over `acgtACGT-_ `."""
 
-    def __init__(self, rows, bandwidth=1000, device=0, window=None, profile=False, threads=None, fill=None, waves=None, slack=None):
+    def __init__(self, rows, bandwidth=1000, device=0, window=None, profile=False, fill=None, waves=None, slack=None):
         self._lib = _lib.load()
         self._h = ctypes.c_void_p()
         self.T = len(rows)
@@ -35,8 +35,6 @@ class PWReAligner:
                "pwr_create")
         if window is not None:
             _check(self._lib.pwr_set_option(self._h, b"window", int(window)), "set window")
-        if threads is not None:
-            _check(self._lib.pwr_set_option(self._h, b"threads", int(threads)), "set threads")
         if slack is not None:
             _check(self._lib.pwr_set_option(self._h, b"slack", int(slack)), "set slack")
         if waves is not None:

@@ -69,7 +69,7 @@ def test_argument_and_input_errors(tmp_path):
     with pytest.raises(PwrError):
         PWReAligner([b"acgt"], bandwidth=0)
     g = PWReAligner([b"acgt", b"ac-t"])                    # option ranges (no device call is made)
-    for key, bad in (("window", 0), ("window", 129), ("fill", 2), ("fill", 5), ("waves", 7), ("waves", 16), ("nonsense", 1)):
+    for key, bad in (("window", 0), ("window", 129), ("fill", 0), ("fill", 1), ("fill", 2), ("fill", 5), ("threads", 256), ("waves", 7), ("waves", 16), ("nonsense", 1)):
         with pytest.raises(PwrError) as e:
             g.set_option(key, bad)
         assert e.value.code == -1, (key, bad)

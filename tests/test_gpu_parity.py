@@ -68,7 +68,7 @@ def _row_by_row(name, bw, rounds, oracle, **opts):
     g.close()
 
 
-@pytest.mark.parametrize("fill", [4, 3, 1, 0], ids=["v3", "v2", "wavepipe", "ldsfill"])
+@pytest.mark.parametrize("fill", [4, 3], ids=["v3", "v2"])
 @pytest.mark.parametrize("name,bw,rounds", STEP_CASES, ids=[c[0] for c in STEP_CASES])
 def test_row_by_row_against_oracle(name, bw, rounds, fill, oracle):
     _row_by_row(name, bw, rounds, oracle, fill=fill)
@@ -83,7 +83,7 @@ def test_wave_geometries_row_by_row(name, bw, rounds, waves, fill, oracle):
     _row_by_row(name, bw, rounds, oracle, fill=fill, waves=waves)
 
 
-@pytest.mark.parametrize("fill", [4, 3, 1, 0], ids=["v3", "v2", "wavepipe", "ldsfill"])
+@pytest.mark.parametrize("fill", [4, 3], ids=["v3", "v2"])
 @pytest.mark.parametrize("window", [1, 3, 64])
 def test_batched_rounds_match_sequential_oracle(window, fill, oracle):
     """Speculative batches of any size must give the row-sequential result (commit in row order,
@@ -246,14 +246,14 @@ def test_rows_without_bases_and_unsupported_states():
 
 def test_medium_properties_and_kernel_cross_check():
     """A shape too large for the oracle to follow row by row in the test budget (2.3 k rows x 37 k
-    columns, 8*10^9 cells per round): size-independent properties, and the three fill kernels and two
+    columns, 8*10^9 cells per round): size-independent properties, and the two fill kernels and several
     batch sizes against each other."""
     import numpy as np
     from repeatresolver_amd import datagen as dg
     from repeatresolver_amd.realigner import PWReAligner
     rows = [bytes(r) for r in dg.make_msa("tree_medium")]
     ref = None
-    for fill, window, waves in ((4, 8, 17), (4, 8, 5), (4, 4, 9), (3, 8, 5), (4, 1, 5), (1, 4, 9), (3, 8, 9), (3, 8, 4)):
+    for fill, window, waves in ((4, 8, 17), (4, 8, 5), (4, 4, 9), (3, 8, 5), (4, 1, 5), (3, 8, 9), (3, 8, 4)):
         g = PWReAligner(rows, bandwidth=1000, fill=fill, window=window, waves=waves)
         g.trim_ends()
         before = [r.replace(b"-", b"").replace(b" ", b"") for r in g.export_rows()]
