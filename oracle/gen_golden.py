@@ -5,8 +5,10 @@ inputs.  Only data is committed: the input MSA, the bytes of the reference's out
 fact that it wrote none), its exit code and its stdout score lines.  Runs only where the
 reference exists (the build container); the GPU box sees just the fixtures.
 
-    python oracle/gen_golden.py            # regenerate everything
+    python oracle/gen_golden.py                 # regenerate the small fixtures (cases.json + *.gz)
+    python oracle/gen_golden.py --transposon    # transposon_like.json: digest-only fixture of a run to convergence
 """
+import hashlib
 import gzip
 import json
 import os
@@ -128,5 +130,22 @@ def main():
                    "cases": cases}, f, indent=1)
 
 
+def transposon():
+    """BASELINE.json configs[4] stand-in at a size whose output (21 MB) is not worth committing: the input is
+    regenerated from its seed wherever the test runs, the fixture holds digests and the reference's score lines."""
+    inp = msa_bytes(dg.make_msa("transposon_like"))
+    rc, out, lines = run_ref(inp, [])
+    fx = {"generator": "oracle/gen_golden.py --transposon", "reference_build": "gcc -O2 -mcmodel=medium PW_ReAligner.c",
+          "workload": "transposon_like", "bandwidth": 1000, "exit_code": rc, "stdout": lines,
+          "input_sha256": hashlib.sha256(inp).hexdigest(), "input_bytes": len(inp),
+          "output_sha256": hashlib.sha256(out).hexdigest(), "output_bytes": len(out)}
+    with open(os.path.join(OUT, "transposon_like.json"), "w") as f:
+        json.dump(fx, f, indent=1)
+    print(fx)
+
+
 if __name__ == "__main__":
-    main()
+    if "--transposon" in sys.argv[1:]:
+        transposon()
+    else:
+        main()

@@ -535,3 +535,12 @@ const int *pwo_dbg_newcol(const pwo_state *s) { return s->newcol; }
 const unsigned char *pwo_dbg_newins(const pwo_state *s) { return s->newins; }
 int pwo_dbg_entry(const pwo_state *s) { return s->entry; }
 uint64_t pwo_dbg_M(const pwo_state *s, int x, int j) { return Mrow(s, x)[j]; }
+
+int pwo_row_columns(const pwo_state *s, int k, int *out, int cap)
+{
+    int n = 0;
+    if (k < 0 || k >= s->T) return -1;
+    for (int i = 0; i < s->W; i++)
+        if (col_sym(s, s->order[i])[k] < 4) { if (n < cap) out[n] = i; n++; }
+    return n;
+}

@@ -43,6 +43,10 @@ void pwo_export(const pwo_state *s, unsigned char *out); /* PW:1556-1598: T*W ch
  * Returns the exit code the reference would use. max_rounds < 0 = unlimited (10000 like PW:1681). */
 int pwo_run(const char *in_path, const char *out_path, int bandwidth, FILE *log, int max_rounds);
 
+/* column ordinals (current numbering; call pwo_compact first for the compacted one) of the bases of row k, left to
+ * right; returns their number (at most cap are written) */
+int pwo_row_columns(const pwo_state *s, int k, int *out, int cap);
+
 /* ---- introspection for kernel-level parity tests (state of the LAST pwo_realign_row call) ---- */
 int pwo_dbg_L(const pwo_state *s);
 int pwo_dbg_W_at_fill(const pwo_state *s);

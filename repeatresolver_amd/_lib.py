@@ -66,6 +66,8 @@ def load():
                                        ctypes.POINTER(ci), ctypes.POINTER(ci), ci]
     lib.pwr_debug_fill_clock.restype = ci
     lib.pwr_debug_fill_clock.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    lib.pwr_debug_row_columns.restype = ci
+    lib.pwr_debug_row_columns.argtypes = [vp, ci, ctypes.POINTER(ci), ci]
     lib.pwr_debug_rounds.restype = ci
     lib.pwr_debug_rounds.argtypes = [vp]
     _lib = lib

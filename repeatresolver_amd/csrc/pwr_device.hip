@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "pwr.h"
@@ -98,6 +99,7 @@ struct JobBufs {
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
     unsigned long long *gtr;       // [njobs][TRK]    k_trace_par: hand-over words of the chunks
     unsigned trace_tag;            // 22-bit launch tag of those words
+    unsigned long long *diag;      // [njobs][32][16] per-wave counters of k_fill_v3 (only written when built with -DPWR_DIAG)
     int njobs_launched;
     int Lmax, colcap, NC;
     size_t dirstride;
@@ -829,10 +831,28 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
 // neighbour by one poll of the fetcher (a few DP rows), and the L2 round trip is never on its critical path.
 // Ring words keep their row tags, so an old occupant of a slot is never mistaken for the row in demand.
 // ---------------------------------------------------------------------------------------------
+#ifndef PWR_INTERIOR_CLS
+#define PWR_INTERIOR_CLS 0          // (4: interior groups run the RIGHT code, experiment on the effect of equal speeds)
+#endif
 #define V3_TICKS() ((unsigned)(__builtin_amdgcn_s_memtime() >> 10))   // 32-bit time in units of 1024 shader clocks (scalar compares)
 #define V3_TIMEOUT_TICKS (1u << 23)                  // a few seconds: how long a wave waits for its neighbour before it flags the job
 #define V4_RB 128                                    // ring slots (rows); the fetcher looks at most 64 rows ahead
 
+#ifdef PWR_DIAG
+#define DG_DECL unsigned long long dg_wait_fast = 0, dg_wait_gen = 0, dg_wait_setup = 0, dg_t = 0, dg_t2 = 0, dg_cyc_int = 0, dg_cyc_gen16 = 0, dg_ts1 = 0, dg_ts2 = 0; unsigned dg_int = 0, dg_gen16 = 0, dg_general = 0, dg_nowork = 0, dg_runs = 0, dg_switch = 0;
+#define DG_T0() dg_t = __builtin_amdgcn_s_memtime();
+#define DG_ADD(ACC) ACC += __builtin_amdgcn_s_memtime() - dg_t;
+#define DG_INC(CNT, N) CNT += (N);
+#define DG_T2() dg_t2 = __builtin_amdgcn_s_memtime();
+#define DG_ADD2(ACC) ACC += __builtin_amdgcn_s_memtime() - dg_t2;
+#else
+#define DG_T2()
+#define DG_ADD2(ACC)
+#define DG_DECL
+#define DG_T0()
+#define DG_ADD(ACC)
+#define DG_INC(CNT, N)
+#endif
 template <int NW, int C>
 __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 {
@@ -860,25 +880,34 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     int *const abortf = &m->abort;
 #define GLD(PTR) __hip_atomic_load((PTR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GST(PTR, VAL, ROW) __hip_atomic_store((PTR), ((unsigned long long)(tagbase | (unsigned)((ROW) + 1)) << 32) | (unsigned)(VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GST2(PTR, VAL, TAG) __hip_atomic_store((PTR), ((unsigned long long)(TAG) << 32) | (unsigned)(VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define TAGOF(W64) ((unsigned)((W64) >> 32))
 #define LLD(REF) __hip_atomic_load(&(REF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define LST(REF, V) __hip_atomic_store(&(REF), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
     if (role == 1) {
         // ---- fetcher
-        while (true) {
+        // One poll = one L2 round trip (the abort flag is looked at every 16th poll, in the same batch of loads); the lag of
+        // a worker behind its neighbour is this loop's period, and it is paid NW - 1 times per lap of the ring of waves.
+        for (unsigned it = 0;; ++it) {
             if (UNI(LLD(wdone))) break;
             const int wx = UNI(LLD(wprog));
             const int r = wx - 1 + lane;                                          // row wx needs words of row wx - 1 too
-            if (r >= 0 && r < L) {
-                const unsigned long long p = GLD(gleftw + 2 * (size_t)r), q = GLD(gleftw + 2 * (size_t)r + 1), t = GLD(gpt + r);
+            const bool inr = r >= 0 && r < L;
+            unsigned long long p = 0, q = 0, t = 0;
+            int ab = 0;
+            if (inr) { p = GLD(gleftw + 2 * (size_t)r); q = GLD(gleftw + 2 * (size_t)r + 1); t = GLD(gpt + r); }
+            if ((it & 15u) == 15u) ab = GLD(abortf);
+            if (inr) {
                 const unsigned tagr = tagbase | (unsigned)(r + 1);
-                if (TAGOF(p) == tagr && TAGOF(q) == tagr) { LST(rP[r & (V4_RB - 1)], p); LST(rM[r & (V4_RB - 1)], q); }   // P before M
+                if (TAGOF(p) == tagr && TAGOF(q) == tagr) {
+                    LST(rP[r & (V4_RB - 1)], p);
+                    __hip_atomic_store(&rM[r & (V4_RB - 1)], q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // P before M: M's tag vouches for both
+                }
                 if (TAGOF(t) == tagr) LST(rT[r & (V4_RB - 1)], t);
             }
             // (no time-out of its own: the worker has one, and its end -- wdone -- or the job's abort flag end this loop)
-            if (UNI(GLD(abortf))) break;
-            __builtin_amdgcn_s_sleep(2);
+            if (UNI(ab)) break;
         }
         return;
     }
@@ -963,139 +992,216 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         }                                                                                        \
     }
 
+    DG_DECL
     bool dead = false;
     while (x < L && !dead) {
         ran_prev = UNI(ran_prev); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); ms = UNI(ms); cs = UNI(cs); gleft = UNI(gleft);
         x = UNI(x);
-        // ---- fast path: runs of ordinary rows (flagged by the gather), as in k_fill_v2
+        // ---- fast path: a RUN of ordinary rows (flagged by the gather), from x to the first row that is not ordinary.
+        // What a row needs beyond its cells is reduced to the hand-over: the left neighbour's self-validating words are
+        // taken from the ring before the scan and checked after it, where the wave waits if they are not there yet -- so it
+        // trails its neighbour by a few rows only.  Rows are processed in their 16-row groups (one 32-bit word of traceback
+        // bits per column and group); a complete group whose rows all play the same role runs as straight-line code:
+        //   INTERIOR  the macro-strip lies inside the band, it is neither the band's first nor its last: no band guards;
+        //   RIGHT     the band ends in the macro-strip: guard y < band end, the row minimum Ptot is posted as well;
+        //   LEFT      the band starts in the macro-strip: guard y >= anf, nothing is needed from the neighbour;
+        // anything else (a change of role inside the group, a partial group) takes the same code with run-time flags.
+        // All roles must cost about the same: a wave that is slower than its neighbour while it is the band's last strip
+        // falls behind for good, and every row of lag per hop is paid NW - 1 times per lap of the ring (measured).
         if (ran_prev && x < L - 1) {
-            if ((x >> 4) != gacc) { V4_FLUSH() gacc = x >> 4; }
-            unsigned mlast_v = (unsigned)LLD(rM[(x - 1) & (V4_RB - 1)]);          // M_last(x-1) of the left neighbour
-            const int y0f = lo + ms * MS;
-            const int rel00 = y0f + lc;
-            const int xstop = UNI(min(L - 1, ((blk + 1) << 6) - 1));
-            const int x_in = x;
-            V4_ALIGN_ACC(x & 15)
-            unsigned db = (unsigned)__builtin_amdgcn_readlane((int)dca, x & 63);        // {anf, base << 24} of row x
-            int sgr[C];
-#pragma unroll
-            for (int i = 0; i < C; ++i) sgr[i] = ldsS1[cs][min(db >> 24, 3u)][lc + i];
-#pragma unroll
-            for (int i = 0; i < C; ++i) asm volatile("" : "+v"(sgr[i]));
-            asm volatile("" : "+v"(mlast_v));
-            int cnt = xstop - x - 1;
-            unsigned goff = (unsigned)x * 16u;                                       // byte offset of row x's words in gmy, kept in a VGPR
-            asm volatile("" : "+v"(goff));
-            auto fast_row = [&](const int fl, const unsigned dbn) __attribute__((always_inline)) {
-                const int af = (int)(db & 0xffffffu);
-                const int Bxf = min(B, W - af);
-                db = dbn;
-                const int Mleft_v = (fl & 4) ? (int)mlast_v : (int)PWR_INF;
-                const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft_v, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
-                const int rel0 = rel00 - af;
-                int tg[C];
-                int run = FBIG;
-#pragma unroll
-                for (int i = 0; i < C; ++i) {
-                    const int pm1 = i ? (int)Mprev[i > 0 ? i - 1 : 0] : pm1_0;
-                    const int d = pm1 + sgr[i];
-                    const int u = (int)Mprev[i] + ug[i];
-                    accC[i] = acc_push(accC[i], __builtin_amdgcn_sicmp(d, u, ICMP_SLE));
-                    const int t3 = min(min(d, u), ig[i]);
-                    tg[i] = ((unsigned)(rel0 + i) < (unsigned)Bxf) ? t3 : FBIG;
-                    run = min(run, tg[i]);
-                }
-                // the neighbour's words of this row, from the ring (M first: the fetcher stores it last)
-                unsigned long long fM = LLD(rM[x & (V4_RB - 1)]);
-                unsigned fP = __hip_atomic_load((unsigned *)&rP[x & (V4_RB - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __builtin_amdgcn_sched_barrier(0);
-#define V4_SCAN_STEP(CTRL, RMASK) { const int t_ = __builtin_amdgcn_update_dpp(PWR_BIG, incl, CTRL, RMASK, 0xF, false); incl = min(incl, t_); }
-#define V4_FENCE() __builtin_amdgcn_sched_barrier(0)
-                int incl = run;
-                V4_SCAN_STEP(DPP_ROW_SHR(1), 0xF) V4_FENCE();
-                const unsigned sxn = min(db >> 24, 3u);
-                V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(2), 0xF) V4_FENCE();
-                const int *const srow = &ldsS1[cs][sxn][lc];
-                V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(4), 0xF) V4_FENCE();
-#pragma unroll
-                for (int i = 0; i < C; ++i) sgr[i] = srow[i];
-                V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(8), 0xF) V4_FENCE();
-                const unsigned tagx = tagbase | (unsigned)(x + 1);
-                V4_FENCE(); V4_SCAN_STEP(DPP_ROW_BCAST15, 0xA) V4_FENCE();
-                unsigned long long *const gq = (unsigned long long *)((char *)gmy + goff);      // this row's two words
-                V4_FENCE(); V4_SCAN_STEP(DPP_ROW_BCAST31, 0xC) V4_FENCE();
-#undef V4_SCAN_STEP
-#undef V4_FENCE
-                const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
-                if (fl & 2) {
-                    if (UNI(TAGOF(fM)) != tagx) {
-                        // not there yet: wait for the fetcher to deliver it (bounded by a time-out that flags the job)
+            unsigned long long bOm = __builtin_amdgcn_ballot_w64((dcf & 1u) != 0);
+            if ((bOm >> (x & 63)) & 1ull) {
+                unsigned long long bPm = __builtin_amdgcn_ballot_w64((dcf & 2u) != 0);       // needs the neighbour's running minimum
+                unsigned long long bMm = __builtin_amdgcn_ballot_w64((dcf & 4u) != 0);       // left score = neighbour's M_last(x-1)
+                unsigned long long bTm = __builtin_amdgcn_ballot_w64((dcf & 8u) != 0);       // the band ends here: post Ptot
+                // per row of the 64-block, one lane each: anf, band end, byte offset of the row's base in the LDS table
+                int dcaf = (int)(dca & 0xffffffu), dcb = min(dcaf + B, W);
+                unsigned dcs = min(dca >> 24, 3u) * (unsigned)(MS * 4);
+                if ((x >> 4) != gacc) { V4_FLUSH() gacc = x >> 4; }
+                V4_ALIGN_ACC(x & 15)
+                if (lane == 0) LST(wprog, x);                                    // the fetcher looks at the rows [x - 1, x + 63)
+                unsigned mlast_v = 0;                                            // M_last(x-1) of the left neighbour
+                if ((bMm >> (x & 63)) & 1ull) {
+                    const unsigned tagp = tagbase | (unsigned)x;
+                    unsigned long long w_ = LLD(rM[(x - 1) & (V4_RB - 1)]);
+                    if (UNI(TAGOF(w_)) != tagp) {                                   // (bounded by a time-out that flags the job)
+                        DG_T0()
                         const unsigned t0 = V3_TICKS();
                         for (unsigned spin = 1;; ++spin) {
-                            fM = LLD(rM[x & (V4_RB - 1)]);
-                            fP = __hip_atomic_load((unsigned *)&rP[x & (V4_RB - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (UNI(TAGOF(fM)) == tagx) break;
-                            // time-out: the job is flagged and this loop left after the row -- which is finished with
-                            // whatever is there, nobody will look at the result
-                            if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; cnt = -1; break; }
+                            w_ = LLD(rM[(x - 1) & (V4_RB - 1)]);
+                            if (UNI(TAGOF(w_)) == tagp) break;
+                            if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
                             __builtin_amdgcn_s_sleep(1);
                         }
+                        DG_ADD(dg_wait_setup)
+                        if (dead) break;
                     }
+                    mlast_v = (unsigned)w_;
                 }
-                {
-                    const int P_in_v = (fl & 2) ? (int)fP : PWR_BIG;
-                    const int P_end_v = min(P_in_v, incl);
-                    int p = min(min(P_in_v, excl), FBIG);
+                int ycol[C];                                                     // absolute columns of this lane's cells
 #pragma unroll
-                    for (int i = 0; i < C; ++i) {
-                        accA[i] = acc_push(accA[i], __builtin_amdgcn_sicmp(tg[i], p, ICMP_SGE));
-                        p = min(p, tg[i]);
-                        Mprev[i] = min((unsigned)(gg[i] + p), PWR_INF);
+                for (int i = 0; i < C; ++i) ycol[i] = lo + ms * MS + lc + i;
+                const char *const stab = (const char *)&ldsS1[cs][0][lc];          // + dcs: the row's substitution scores S_b - G
+                int sgr[C];
+                {
+                    const int *const srow0 = (const int *)(stab + __builtin_amdgcn_readlane((int)dcs, x & 63));
+#pragma unroll
+                    for (int i = 0; i < C; ++i) sgr[i] = srow0[i];
+                }
+                int af_done = a_prev;
+                DG_INC(dg_runs, 1)
+                while (true) {
+                    const int r_beg = x & 15, g0 = x - r_beg, r0 = g0 & 63;
+                    int nrun = __builtin_ctz(~((unsigned)(bOm >> (r0 + r_beg)) & 0xffffu) | (1u << (16 - r_beg)));   // ordinary rows from x on, within the group
+                    nrun = min(nrun, L - 1 - x);
+                    if (nrun <= 0) break;
+                    const unsigned nPm = (unsigned)(bPm >> r0) & 0xffffu, kMm = (unsigned)(bMm >> r0) & 0xffffu, eTm = (unsigned)(bTm >> r0) & 0xffffu;
+                    int cls = 3;
+                    if (nrun == 16) {
+                        if (nPm == 0xffffu && kMm == 0xffffu) cls = eTm == 0u ? 0 : (eTm == 0xffffu ? 1 : 3);
+                        else if ((nPm | kMm | eTm) == 0u) cls = 2;
                     }
-                    mlast_v = (unsigned)fM;
-                    if (lane == 63) {
-                        GST(gq, P_end_v, x);
-                        GST(gq + 1, Mprev[C - 1], x);
-                        if (fl & 8) GST(gpt + x, P_end_v, x);
+                    if (gacc < 0) gacc = x >> 4;
+#ifdef PWR_DIAG
+                    if (!dg_ts1 && x >= 1024) dg_ts1 = __builtin_amdgcn_s_memrealtime();
+                    if (!dg_ts2 && x >= 2048) dg_ts2 = __builtin_amdgcn_s_memrealtime();
+#endif
+                    unsigned long long *const gq0 = gmy + 2 * (size_t)g0, *const gpt0 = gpt + g0;
+                    const unsigned long long *const ringM = &rM[g0 & (V4_RB - 1)], *const ringP = &rP[g0 & (V4_RB - 1)];   // the group's 16 consecutive slots
+                    auto group_row = [&](const int r, auto cls_) __attribute__((always_inline)) {
+                        constexpr int CLS = decltype(cls_)::value;                 // 0 INTERIOR, 1 RIGHT, 2 LEFT, 3 run-time flags
+                        const int xr = g0 + r;
+                        bool bP = CLS <= 1 || CLS == 4, bM = CLS <= 1 || CLS == 4, bT = CLS == 1;
+                        if (CLS == 3) { bP = (nPm >> r) & 1u; bM = (kMm >> r) & 1u; bT = (eTm >> r) & 1u; }
+                        int af = 0, bend = 0;
+                        if (CLS >= 2) af = __builtin_amdgcn_readlane(dcaf, r0 + r);
+                        if (CLS == 1 || CLS == 3 || CLS == 4) bend = __builtin_amdgcn_readlane(dcb, r0 + r);
+                        const int Mleft_v = bM ? (int)mlast_v : (int)PWR_INF;
+                        const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft_v, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
+                        int tg[C];
+                        int run = FBIG;
+#pragma unroll
+                        for (int i = 0; i < C; ++i) {
+                            const int pm1 = i ? (int)Mprev[i > 0 ? i - 1 : 0] : pm1_0;
+                            const int d = pm1 + sgr[i];
+                            const int u = (int)Mprev[i] + ug[i];
+                            accC[i] = acc_push(accC[i], __builtin_amdgcn_sicmp(d, u, ICMP_SLE));
+                            const int t3 = min(min(d, u), ig[i]);
+                            bool inb = true;
+                            if (CLS == 1 || CLS == 4) inb = ycol[i] < bend;
+                            if (CLS == 2) inb = ycol[i] >= af;
+                            if (CLS == 3) inb = (unsigned)(ycol[i] - af) < (unsigned)(bend - af);
+                            tg[i] = inb ? t3 : FBIG;
+                            run = min(run, tg[i]);
+                        }
+                        // the neighbour's words of this row, from the ring: M (with the tag) first, the fetcher stores it last
+                        unsigned long long fM = 0;
+                        unsigned fP = 0;
+                        if (CLS != 2) {
+                            fM = LLD(ringM[r]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            fP = __hip_atomic_load((const unsigned *)&ringP[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#define V4_SCAN_STEP(CTRL, RMASK) { const int t_ = __builtin_amdgcn_update_dpp(PWR_BIG, incl, CTRL, RMASK, 0xF, false); incl = min(incl, t_); }
+#define V4_FENCE() __builtin_amdgcn_sched_barrier(0)
+                        int incl = run;
+                        V4_SCAN_STEP(DPP_ROW_SHR(1), 0xF) V4_FENCE();
+                        const int soff = __builtin_amdgcn_readlane((int)dcs, min(r0 + r + 1, 63));    // (past the block's end: reloaded below)
+                        V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(2), 0xF) V4_FENCE();
+                        const int *const srow = (const int *)(stab + soff);
+                        V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(4), 0xF) V4_FENCE();
+#pragma unroll
+                        for (int i = 0; i < C; ++i) sgr[i] = srow[i];
+                        V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(8), 0xF) V4_FENCE();
+                        const unsigned tagx = tagbase | (unsigned)(xr + 1);
+                        V4_FENCE(); V4_SCAN_STEP(DPP_ROW_BCAST15, 0xA) V4_FENCE();
+                        V4_FENCE(); V4_SCAN_STEP(DPP_ROW_BCAST31, 0xC) V4_FENCE();
+#undef V4_SCAN_STEP
+#undef V4_FENCE
+                        if (bP && __builtin_expect(UNI(TAGOF(fM)) != tagx, 0)) {
+                            // not there yet: wait for the fetcher to deliver it (bounded by a time-out that flags the job)
+                            DG_T0()
+                            const unsigned t0 = V3_TICKS();
+                            for (unsigned spin = 1;; ++spin) {
+                                fM = LLD(ringM[r]);
+                                __builtin_amdgcn_sched_barrier(0);
+                                fP = __hip_atomic_load((const unsigned *)&ringP[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (UNI(TAGOF(fM)) == tagx) break;
+                                // time-out: the job is flagged and the loop left after this row -- which is finished with whatever
+                                // is there, nobody will look at the result
+                                if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            DG_ADD(dg_wait_fast)
+                        }
+                        const int P_in_v = bP ? (int)fP : PWR_BIG;
+                        const int P_end_v = min(P_in_v, incl);
+                        const int pq = min(P_in_v, FBIG);
+                        int p = min(__builtin_amdgcn_update_dpp(pq, incl, DPP_WAVE_SHR1, 0xF, 0xF, false), pq);
+#pragma unroll
+                        for (int i = 0; i < C; ++i) {
+                            accA[i] = acc_push(accA[i], __builtin_amdgcn_sicmp(tg[i], p, ICMP_SGE));
+                            p = min(p, tg[i]);
+                            Mprev[i] = min((unsigned)(gg[i] + p), PWR_INF);
+                        }
+                        mlast_v = (unsigned)fM;
+                        if (lane == 63) {
+                            GST2(gq0 + 2 * r, P_end_v, tagx);
+                            GST2(gq0 + 2 * r + 1, Mprev[C - 1], tagx);
+                            if (bT) GST2(gpt0 + r, P_end_v, tagx);
+                        }
+                    };
+                    int r_end = r_beg + nrun;
+                    DG_T2()
+                    if (cls == 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, PWR_INTERIOR_CLS>{});
+                        DG_INC(dg_int, 16)
+                        DG_ADD2(dg_cyc_int)
+                    } else if (cls == 1) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 1>{});
+                    } else if (cls == 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 2>{});
+                    } else {
+                        for (int r = r_beg; r < r_end; ++r) {
+                            group_row(r, std::integral_constant<int, 3>{});
+                            if (dead) { r_end = r + 1; break; }
+                        }
                     }
-                    ++x; --cnt;
-                    goff += 16u;
-                    if ((x & 15) == 0) {                                             // the 16-row group is complete
+                    if (cls != 0) { DG_INC(dg_gen16, r_end - r_beg) DG_ADD2(dg_cyc_gen16) }
+                    x = g0 + r_end;
+                    af_done = __builtin_amdgcn_readlane(dcaf, (x - 1) & 63);       // anf of the last row done
+                    if ((x & 15) == 0) {                                          // the 16-row group is complete
                         uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;
 #pragma unroll
                         for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; }
-                        gacc = x >> 4;
-                        if (lane == 0) LST(wprog, x);                                // where the fetcher should look
-                    }
-                }
-            };
-            while (true) {
-                x = UNI(x); cnt = UNI(cnt); gacc = UNI(gacc); db = UNI(db);
-                const int fl = __builtin_amdgcn_readlane((int)dcf, x & 63);
-                if ((cnt | ~(fl << 31)) < 0) break;
-                fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dca, (x + 1) & 63));
-            }
-            int alast = x != x_in ? (__builtin_amdgcn_readlane((int)dca, (x - 1) & 63) & 0xffffff) : a_prev;   // anf of the last row done
-            if (!dead && (x & 63) == 63 && x < L - 1) {
-                const int fl = __builtin_amdgcn_readlane((int)dcf, 63);
-                if (fl & 1) {
-                    cnt = 0;
-                    alast = (int)(db & 0xffffffu);
-                    fast_row(fl, (unsigned)__builtin_amdgcn_readlane((int)dna, 0));
-                    if (!dead) V4_ROTATE_BLOCK()
-                }
-            }
-            if (x != x_in) { a_prev = alast; Bx_prev = min(B, W - alast); }         // for the general path, should it take the next row
-            if (dead) {                                                              // the unfinished row's C flags
+                        gacc = -1; nacc = 0;
+                    } else nacc = x & 15;
+                    if (dead || x >= L - 1) break;
+                    if ((x >> 6) != blk) {
+                        V4_ROTATE_BLOCK()
+                        bOm = __builtin_amdgcn_ballot_w64((dcf & 1u) != 0); bPm = __builtin_amdgcn_ballot_w64((dcf & 2u) != 0);
+                        bMm = __builtin_amdgcn_ballot_w64((dcf & 4u) != 0); bTm = __builtin_amdgcn_ballot_w64((dcf & 8u) != 0);
+                        dcaf = (int)(dca & 0xffffffu); dcb = min(dcaf + B, W);
+                        dcs = min(dca >> 24, 3u) * (unsigned)(MS * 4);
+                        const int *const srow0 = (const int *)(stab + __builtin_amdgcn_readlane((int)dcs, 0));
 #pragma unroll
-                for (int i = 0; i < C; ++i) accC[i] >>= 1;
-            }
-            if (x != x_in) {
-                nacc = x & 15;
-                a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
-                sx = __builtin_amdgcn_readlane(scur, x & 63);
+                        for (int i = 0; i < C; ++i) sgr[i] = srow0[i];
+                    }
+                    if (lane == 0) LST(wprog, x);
+                }
+                a_prev = af_done; Bx_prev = min(B, W - af_done);
+                if (dead) break;
+                if (x < L) {
+                    if ((x >> 6) != blk) V4_ROTATE_BLOCK()
+                    a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+                    sx = __builtin_amdgcn_readlane(scur, x & 63);
+                }
                 if (lane == 0) LST(wprog, x);
-                if (!dead) continue;                                                 // more ordinary rows, most likely
+                continue;
             }
         }
         if (dead || x >= L) break;
@@ -1116,6 +1222,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 while (ms < ms_lo) ms += NW;
                 V4_LOADS(ms, cs, ug, gg, ig, gleft)
             }
+            DG_INC(dg_switch, 1)
             msn = ms + NW;
             V4_LOADS(msn, cs ^ 1, nu, ng, ni, gleftn)
             ran_prev = 0;
@@ -1123,6 +1230,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         }
         if (ms > ms_hi) {                                   // no work for this wave in row x
             ran_prev = 0;
+            DG_INC(dg_nowork, 1)
             V4_NEXT_ROW()
             continue;
         }
@@ -1134,6 +1242,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         unsigned ePx = 0, ePy = 0, eMy = 0, eTx = 0;
         {
             const unsigned tagx = tagbase | (unsigned)(x + 1), tagp = tagbase | (unsigned)x;
+            DG_T0()
             const unsigned t0 = V3_TICKS();
             for (unsigned spin = 1;; ++spin) {
                 const unsigned long long eQ = LLD(rM[x & (V4_RB - 1)]), eP = LLD(rP[x & (V4_RB - 1)]);
@@ -1145,6 +1254,8 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
+            DG_ADD(dg_wait_gen)
+            DG_INC(dg_general, 1)
             if (dead) break;
         }
         int Mleft = (int)PWR_INF;
@@ -1215,6 +1326,15 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         V4_NEXT_ROW()
     }
     V4_FLUSH()
+#ifdef PWR_DIAG
+    if (lane == 0) {
+        unsigned long long *dgp = jb.diag + ((size_t)job * 32 + wave) * 16;
+        dgp[0] = __builtin_amdgcn_s_memtime() - t_clk0; dgp[1] = dg_wait_fast; dgp[2] = dg_wait_gen; dgp[3] = dg_wait_setup;
+        dgp[4] = ((unsigned long long)dg_int << 32) | dg_gen16; dgp[5] = ((unsigned long long)dg_general << 32) | dg_nowork;
+        dgp[6] = ((unsigned long long)dg_runs << 32) | dg_switch; dgp[7] = (unsigned long long)L;
+        dgp[8] = dg_cyc_gen16; dgp[9] = dg_ts1; dgp[10] = dg_ts2; dgp[11] = dg_cyc_int;
+    }
+#endif
     if (lane == 0) LST(wdone, 1);                                                    // releases the fetcher
     if (dead) {
         if (lane == 0) { __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
@@ -1228,6 +1348,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     }
 #undef GLD
 #undef GST
+#undef GST2
 #undef TAGOF
 #undef LLD
 #undef LST
@@ -1898,6 +2019,14 @@ __global__ __launch_bounds__(256) void k_export(DState st, unsigned char *out, i
     for (int x = threadIdx.x; x < L; x += blockDim.x) o[st.rank[st.pos[off + x]]] = "ACGT"[st.seq[off + x]];
 }
 
+// introspection (tests): ordinals of the bases of one row
+__global__ __launch_bounds__(256) void k_rowcols(DState st, int k, int *out)
+{
+    const long long off = st.rowoff[k];
+    const int L = st.rowlen[k];
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < L; x += gridDim.x * blockDim.x) out[x] = st.rank[st.pos[off + x]];
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -2111,6 +2240,8 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
         c->fill_epoch = 0;
     }
     if ((rc = dmalloc(c, &jb.gtr, (size_t)njobs * 16))) return rc;
+    if ((rc = dmalloc(c, &jb.diag, (size_t)njobs * 32 * 16))) return rc;
+    if (hipMemsetAsync(jb.diag, 0, (size_t)njobs * 32 * 16 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     if (hipMemsetAsync(jb.gtr, 0, (size_t)njobs * 16 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     c->trace_epoch = 0;
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
@@ -2123,7 +2254,7 @@ static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
     dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.rec); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
-    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gpt); dfree(c, jb.gtr); dfree(c, c->d_jobrows);
+    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gpt); dfree(c, jb.gtr); dfree(c, jb.diag); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -2618,6 +2749,25 @@ extern "C" int pwr_debug_last_job(pwr_ctx *c, int *L, int *entry, int *W, int *w
     return PWR_OK;
 }
 
+// column ordinals of the bases of row k, left to right (the counterpart of the oracle's pwo_row_columns); returns the
+// number of bases or a negative error
+extern "C" int pwr_debug_row_columns(pwr_ctx *c, int k, int *out, int cap)
+{
+    if (!c || !c->on_device || k < 0 || k >= c->T || !out) return PWR_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    const int L = c->rowlen[k];
+    if (L == 0) return 0;
+    int *d = nullptr;
+    int rc = dmalloc(c, &d, (size_t)L);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rowcols, dim3(32), dim3(256), 0, c->stream, c->st, k, d);
+    std::vector<int> h(L);
+    if (hipMemcpyAsync(h.data(), d, sizeof(int) * L, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { dfree(c, d); return PWR_ERR_DEVICE; }
+    dfree(c, d);
+    memcpy(out, h.data(), sizeof(int) * std::min(L, cap));
+    return L;
+}
+
 extern "C" int pwr_debug_rounds(pwr_ctx *c)
 {
     if (!c || !c->on_device) return PWR_ERR_ARG;
@@ -2629,6 +2779,16 @@ extern "C" int pwr_debug_rounds(pwr_ctx *c)
 }
 
 // shader clock the fill kernel of job 0 ran at: delta s_memtime / delta s_memrealtime (100 MHz)
+// per-wave counters of the last k_fill_v3 launch's job 0 (dev builds with -DPWR_DIAG): 32 x 8 words
+extern "C" int pwr_debug_fill_diag(pwr_ctx *c, unsigned long long *out)
+{
+    if (!c || !c->on_device || !out) return PWR_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpy(out, c->jb.diag, sizeof(unsigned long long) * 32 * 16, hipMemcpyDeviceToHost));
+    return PWR_OK;
+}
+
 extern "C" int pwr_debug_fill_clock(pwr_ctx *c, double *mhz, double *fill_us)
 {
     if (!c || !c->on_device) return PWR_ERR_ARG;

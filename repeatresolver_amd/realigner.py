@@ -122,6 +122,14 @@ class PWReAligner:
         return {"L": n, "entry": e.value, "W": w.value, "way": list(way[:n]), "newcol": list(nc[:n]),
                 "rounds": self._lib.pwr_debug_rounds(self._h)}
 
+    def debug_row_columns(self, k, cap=40000):
+        """Column ordinals of the bases of row k (tests)."""
+        buf = (ctypes.c_int * cap)()
+        n = self._lib.pwr_debug_row_columns(self._h, k, buf, cap)
+        if n < 0:
+            raise PwrError(n, "pwr_debug_row_columns")
+        return list(buf[:n])
+
     def debug_fill_clock(self):
         mhz, us = ctypes.c_double(), ctypes.c_double()
         _check(self._lib.pwr_debug_fill_clock(self._h, ctypes.byref(mhz), ctypes.byref(us)), "pwr_debug_fill_clock")

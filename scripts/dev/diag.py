@@ -1,0 +1,29 @@
+"""Dev aid (GPU box): per-wave counters of k_fill_v3 for a few single realignments (library built with -DPWR_DIAG).
+usage: diag.py [workload] [rows...]"""
+import ctypes, os, sys
+sys.path.insert(0, ".")
+from repeatresolver_amd import _lib
+_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libpwr_diag.so")
+from repeatresolver_amd import datagen as dg
+from repeatresolver_amd.realigner import PWReAligner
+wl = sys.argv[1] if len(sys.argv) > 1 else "tree_medium"
+ks = [int(v) for v in sys.argv[2:]] or [0, 1, 2]
+rows = [bytes(r) for r in dg.make_msa(wl)]
+g = PWReAligner(rows, bandwidth=1000, window=1)
+g.trim_ends(); g.total_score()
+lib = _lib.load()
+lib.pwr_debug_fill_diag.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
+buf = (ctypes.c_uint64 * 512)()
+for k in ks:
+    g.realign_row(k)
+    mhz, us = g.debug_fill_clock()
+    lib.pwr_debug_fill_diag(g._h, buf)
+    L = buf[7]
+    print(f"row {k}: L={L} fill {us:.1f} us = {1e3*us/max(L,1):.1f} ns/DP row, clock {mhz:.0f} MHz")
+    base1 = min(buf[w*16+9] for w in range(9)); base2 = min(buf[w*16+10] for w in range(9))
+    for w in range(9):
+        d = buf[w*16:(w+1)*16]
+        print(f"  wave {w}: reached row 1024 at +{(d[9]-base1)*10} ns, row 2048 at +{(d[10]-base2)*10} ns (after the first wave to get there)")
+        tot = d[0]
+        print(f"  wave {w}: cycles {tot} ({tot/max(L,1):.0f}/row) wait fast {d[1]/max(tot,1):.2%} gen {d[2]/max(tot,1):.2%} setup {d[3]/max(tot,1):.2%} | interior {d[11]/max(d[4]>>32,1):.0f} cyc/row, other fast rows {d[8]/max(d[4]&0xffffffff,1):.0f} cyc/row (incl waits) | rows interior {d[4]>>32} generic {d[4]&0xffffffff} general {d[5]>>32} nowork {d[5]&0xffffffff} runs {d[6]>>32} switches {d[6]&0xffffffff}")
+g.close()

@@ -73,24 +73,89 @@ __global__ void kb(unsigned long long *out, int *sink, int mode) {
     } else if (mode == 24) {  // independent v_cmp e64 + addc pairs on 2 chains
         for (int i = 0; i < N; ++i) { REP32(asm volatile("v_cmp_le_i32_e64 s[20:21], %0, %2\n v_cmp_le_i32_e64 s[24:25], %1, %2\n v_addc_co_u32_e64 %0, s[20:21], %0, %0, s[20:21]\n v_addc_co_u32_e64 %1, s[24:25], %1, %1, s[24:25]" : "+v"(v), "+v"(w2) : "v"(w) : "s20", "s21", "s24", "s25");) }
     }
+    else if (mode == 25) {
+        asm volatile("v_mov_b32 v84, 0\n v_mov_b32 v85, 0\n v_mov_b32 v83, 0\n s_mov_b32 s40, 0\n s_mov_b32 s44, 0\n s_mov_b32 s45, 0\n s_mov_b32 s46, 0x3fffffff\n s_mov_b64 s[42:43], 0\n s_bitset1_b32 s43, 31\n v_mov_b32 v89, 0\n" ::: "v60","v61","v62","v63","v69","v70","v71","v72","v88","v89","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","s40","s42","s43","s44","s45","s46","s47","s48","s49","memory");
+        for (int i = 0; i < N; ++i) { asm volatile(
+    "v_bfrev_b32_e32 v70, -2\n s_nop 1\n v_mov_b32_dpp v70, v69 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+    "s_waitcnt lgkmcnt(1)\n v_min3_i32 v70, v60, v70, s46\n v_cmp_ge_i32_e64 s[48:49], v71, v70\n v_addc_co_u32_e64 v72, s[48:49], v72, v72, s[48:49]\n"
+    "v_min_i32_e32 v70, v70, v71\n v_cmp_ge_i32_e64 s[48:49], v88, v70\n v_min_i32_e32 v88, v70, v88\n v_add_u32_e32 v88, v89, v88\n v_min_u32_e32 v88, 2.0, v88\n"
+    "v_addc_co_u32_e64 v75, s[48:49], v75, v75, s[48:49]\n"
+    
+    "v_add_u32_e32 v60, v76, v70\n v_min_u32_e32 v60, 2.0, v60\n v_mov_b32_dpp v61, v88 wave_shr:1 row_mask:0xf bank_mask:0xf\n s_waitcnt lgkmcnt(0)\n"
+    "v_add_u32_e32 v61, v62, v61\n v_add_u32_e32 v62, v77, v60\n v_cmp_le_i32_e64 s[48:49], v61, v62\n v_min3_i32 v71, v61, v62, v78\n v_add_u32_e32 v62, v63, v60\n"
+    "v_mov_b32_e32 v60, s45\n ds_read_b64 v[60:61], v60 offset:24\n v_add_u32_e32 v63, v79, v88\n v_addc_co_u32_e64 v80, s[48:49], v80, v80, s[48:49]\n"
+    "v_min3_i32 v88, v62, v63, v81\n v_cmp_le_i32_e64 s[48:49], v62, v63\n v_min3_i32 v69, v71, v88, s46\n v_addc_co_u32_e64 v82, s[48:49], v82, v82, s[48:49]\n"
+    "s_nop 1\n v_min_i32_dpp v69, v69, v69 row_shr:1 row_mask:0xf bank_mask:0xf\n s_or_b32 s48, s40, 4\n v_readlane_b32 s48, v83, s48\n s_lshr_b32 s48, s48, 24\n s_min_u32 s48, s48, 3\n"
+    "v_min_i32_dpp v69, v69, v69 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_min_i32_dpp v69, v69, v69 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+    "v_lshl_add_u32 v62, s48, 9, v84\n ds_read_b64 v[62:63], v62\n v_min_i32_dpp v69, v69, v69 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+    "v_min_i32_dpp v69, v69, v69 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n v_min_i32_dpp v69, v69, v69 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+ :: [gp] "s"(sink) : "v60","v61","v62","v63","v69","v70","v71","v72","v88","v89","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","s40","s42","s43","s44","s45","s46","s47","s48","s49","memory"); }
+    }
+    else if (mode == 26) {
+        asm volatile("v_mov_b32 v84, 0\n v_mov_b32 v85, 0\n v_mov_b32 v83, 0\n s_mov_b32 s40, 0\n s_mov_b32 s44, 0\n s_mov_b32 s45, 0\n s_mov_b32 s46, 0x3fffffff\n s_mov_b64 s[42:43], 0\n s_bitset1_b32 s43, 31\n v_mov_b32 v89, 0\n" ::: "v60","v61","v62","v63","v69","v70","v71","v72","v88","v89","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","s40","s42","s43","s44","s45","s46","s47","s48","s49","memory");
+        for (int i = 0; i < N; ++i) { asm volatile(
+    "v_bfrev_b32_e32 v70, -2\n s_nop 1\n v_mov_b32_dpp v70, v69 wave_shr:1 row_mask:0xf bank_mask:0xf\n"
+    "s_waitcnt lgkmcnt(1)\n v_min3_i32 v70, v60, v70, s46\n v_cmp_ge_i32_e64 s[48:49], v71, v70\n v_addc_co_u32_e64 v72, s[48:49], v72, v72, s[48:49]\n"
+    "v_min_i32_e32 v70, v70, v71\n v_cmp_ge_i32_e64 s[48:49], v88, v70\n v_min_i32_e32 v88, v70, v88\n v_add_u32_e32 v88, v89, v88\n v_min_u32_e32 v88, 2.0, v88\n"
+    "v_addc_co_u32_e64 v75, s[48:49], v75, v75, s[48:49]\n"
+    "s_and_saveexec_b64 s[48:49], s[42:43]\n s_cbranch_execz 9f\n s_or_b32 s47, s40, s44\n v_min_i32_e32 v86, v60, v69\n v_mov_b32_e32 v87, s47\n v_mov_b32_e32 v89, s47\n"
+    "global_store_dwordx2 v85, v[86:87], %[gp] offset:32 sc1\n global_store_dwordx2 v85, v[88:89], %[gp] offset:40 sc1\n 9:\n s_or_b64 exec, exec, s[48:49]\n"
+    "v_add_u32_e32 v60, v76, v70\n v_min_u32_e32 v60, 2.0, v60\n v_mov_b32_dpp v61, v88 wave_shr:1 row_mask:0xf bank_mask:0xf\n s_waitcnt lgkmcnt(0)\n"
+    "v_add_u32_e32 v61, v62, v61\n v_add_u32_e32 v62, v77, v60\n v_cmp_le_i32_e64 s[48:49], v61, v62\n v_min3_i32 v71, v61, v62, v78\n v_add_u32_e32 v62, v63, v60\n"
+    "v_mov_b32_e32 v60, s45\n ds_read_b64 v[60:61], v60 offset:24\n v_add_u32_e32 v63, v79, v88\n v_addc_co_u32_e64 v80, s[48:49], v80, v80, s[48:49]\n"
+    "v_min3_i32 v88, v62, v63, v81\n v_cmp_le_i32_e64 s[48:49], v62, v63\n v_min3_i32 v69, v71, v88, s46\n v_addc_co_u32_e64 v82, s[48:49], v82, v82, s[48:49]\n"
+    "s_nop 1\n v_min_i32_dpp v69, v69, v69 row_shr:1 row_mask:0xf bank_mask:0xf\n s_or_b32 s48, s40, 4\n v_readlane_b32 s48, v83, s48\n s_lshr_b32 s48, s48, 24\n s_min_u32 s48, s48, 3\n"
+    "v_min_i32_dpp v69, v69, v69 row_shr:2 row_mask:0xf bank_mask:0xf\n s_nop 1\n v_min_i32_dpp v69, v69, v69 row_shr:4 row_mask:0xf bank_mask:0xf\n"
+    "v_lshl_add_u32 v62, s48, 9, v84\n ds_read_b64 v[62:63], v62\n v_min_i32_dpp v69, v69, v69 row_shr:8 row_mask:0xf bank_mask:0xf\n s_nop 1\n"
+    "v_min_i32_dpp v69, v69, v69 row_bcast:15 row_mask:0xa bank_mask:0xf\n s_nop 1\n v_min_i32_dpp v69, v69, v69 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+ :: [gp] "s"(sink) : "v60","v61","v62","v63","v69","v70","v71","v72","v88","v89","v75","v76","v77","v78","v79","v80","v81","v82","v83","v84","v85","v86","v87","s40","s42","s43","s44","s45","s46","s47","s48","s49","memory"); }
+    }
     unsigned long long t1 = __builtin_readcyclecounter();
     if (threadIdx.x == 0) out[blockIdx.x] = t1 - t0;
     sink[threadIdx.x] = v + w + s + w2;
+}
+
+// cross-work-group hand-over latency: block A stores a sequence number (agent scope), block B polls it and answers
+__global__ void kpp(unsigned long long *out, unsigned long long *mail, int partner, int iters) {
+    if (blockIdx.x != 0 && (int)blockIdx.x != partner) return;
+    if (threadIdx.x != 0) return;
+    unsigned long long *a = mail, *b = mail + 32;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    if (blockIdx.x == 0) {
+        for (int i = 1; i <= iters; ++i) {
+            __hip_atomic_store(a, (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)i) {}
+        }
+        out[0] = __builtin_readcyclecounter() - t0;
+    } else {
+        for (int i = 1; i <= iters; ++i) {
+            while (__hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)i) {}
+            __hip_atomic_store(b, (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 int main() {
     unsigned long long *d; int *sink; hipMalloc(&d, 64); hipMalloc(&sink, 4096);
     const char *names[] = {"dep v_add", "2 indep v_add (pair)", "readfirstlane+s_add+v_mov (3)", "dep s_add", "s_branch taken(+skip nop)",
         "s_nop1 + dpp min", "ds_read chase (+waitcnt+shl)", "v_cmp+v_cndmask (2)", "v_cmp+saveexec+v_add+restore (4)", "ds_write+ds_read+wait (3)",
-        "readlane+s_cmp+cbranch nt+v_add (4)", "s_cmp+cbranch taken (2)", "dep v_min3", "s_memtime+wait", "s_barrier", "ds_write+wait", "indep readfirstlane", "s_add + v_add sgpr (2)", "v_cmp_e64 sgpr + v_addc sgpr (2)", "v_cmp vcc + v_addc vcc (2)", "v_readlane + v_add sgpr (2)", "v_cmp_e64 sgpr + v_cndmask sgpr (2)", "global_store_dword", "saveexec + v_add + restore (3)", "2x(v_cmp_e64) + 2x(v_addc) indep (4)"};
+        "readlane+s_cmp+cbranch nt+v_add (4)", "s_cmp+cbranch taken (2)", "dep v_min3", "s_memtime+wait", "s_barrier", "ds_write+wait", "indep readfirstlane", "s_add + v_add sgpr (2)", "v_cmp_e64 sgpr + v_addc sgpr (2)", "v_cmp vcc + v_addc vcc (2)", "v_readlane + v_add sgpr (2)", "v_cmp_e64 sgpr + v_cndmask sgpr (2)", "global_store_dword", "saveexec + v_add + restore (3)", "2x(v_cmp_e64) + 2x(v_addc) indep (4)", "interior DP row as compiled, no publish (x32 = one row)", "interior DP row as compiled, with publish (x32 = one row)"};
     for (int threads = 64; threads <= 64; threads += 256)
-    for (int m = 0; m < 25; ++m) {
+    for (int m = 0; m < 27; ++m) {
         hipLaunchKernelGGL(kb, dim3(1), dim3(threads), 0, 0, d, sink, m);
         hipDeviceSynchronize();
         hipLaunchKernelGGL(kb, dim3(1), dim3(threads), 0, 0, d, sink, m);
         unsigned long long h; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
         // s_memtime counts at 100 MHz? report raw ticks per group
         printf("threads %3d mode %2d %-42s ticks/group %.2f\n", threads, m, names[m], (double)h / (N * 32.0)); fflush(stdout);
+    }
+    unsigned long long *mail; hipMalloc(&mail, 4096);
+    for (int partner : {1, 2, 8, 9, 16, 64, 255}) {
+        hipMemset(mail, 0, 4096);
+        hipLaunchKernelGGL(kpp, dim3(256), dim3(64), 0, 0, d, mail, partner, 2000);
+        hipDeviceSynchronize();
+        unsigned long long h; hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost);
+        printf("ping-pong block 0 <-> block %3d: %.0f cycles per one-way hand-over (store sc1 -> polling load sc1)\n", partner, (double)h / 4000.0); fflush(stdout);
     }
     return 0;
 }

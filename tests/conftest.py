@@ -51,6 +51,8 @@ class Oracle:
             getattr(lib, n).argtypes = [vp]
         lib.pwo_row_length.restype = ci
         lib.pwo_row_length.argtypes = [vp, ci]
+        lib.pwo_row_columns.restype = ci
+        lib.pwo_row_columns.argtypes = [vp, ci, ctypes.POINTER(ci), ci]
         lib.pwo_cells.restype = u64
         lib.pwo_cells.argtypes = [vp]
         lib.pwo_trim.argtypes = [vp]
@@ -92,6 +94,12 @@ class Oracle:
         h = self.lib.pwo_create(T, W, b"".join(rows), bandwidth)
         assert h, "oracle rejected the input"
         return h
+
+    def row_columns(self, h, k, cap=40000):
+        buf = (ctypes.c_int * cap)()
+        n = self.lib.pwo_row_columns(h, k, buf, cap)
+        assert 0 <= n <= cap
+        return list(buf[:n])
 
     def export(self, h) -> list:
         T, W = self.lib.pwo_rows(h), self.lib.pwo_width(h)

@@ -1,0 +1,123 @@
+"""-m gpu: the HIP path at BASELINE.json's full sizes and on the remaining configs.
+
+configs[1] (Tree_1perc_30000kb, 13 510 rows x 136 477 columns) and configs[2] (Distributed, 200 copies, 60x:
+40 195 rows x 149 140 columns) are far too large to follow to convergence with the CPU oracle inside a test, but the
+oracle does ~30 full-size realignments per second: a PREFIX of round 1 is checked row by row (Way, entry column, new
+placement) and then through speculative batches (pwr_realign_rows), comparing the placement of every realigned row,
+the width, the total score and the reference's cell count.  configs[3]: Window.py sections of a realigned MSA, each
+section on the GPU against the oracle on the same section.  configs[4]: a transposon-sized MSA to convergence
+through the CLI against a fixture made with the compiled reference (tests/golden/transposon_like.json)."""
+import hashlib
+import json
+import os
+
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _prefix_parity(workload, n_single, n_batched, oracle, fill_epoch=None, others=()):
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    rows = [bytes(r) for r in dg.make_msa(workload)]
+    lib = oracle.lib
+    g = PWReAligner(rows, bandwidth=1000)
+    g.trim_ends()
+    h = oracle.create(rows, 1000)
+    T = len(rows)
+    del rows
+    lib.pwo_trim(h)
+    assert g.dims() == (lib.pwo_rows(h), lib.pwo_width(h))
+    assert g.total_score() == lib.pwo_total_score(h)
+    # (1) one realignment at a time: every kernel's output against the oracle
+    for k in range(n_single):
+        assert lib.pwo_realign_row(h, k) == 0
+        g.realign_row(k)
+        L = lib.pwo_dbg_L(h)
+        if L == 0:
+            continue
+        d = g.debug_last_job()
+        assert d["L"] == L, k
+        assert d["W"] == lib.pwo_dbg_W_at_fill(h), k
+        assert d["way"] == [lib.pwo_dbg_way(h)[x] for x in range(L)], k
+        assert d["entry"] == lib.pwo_dbg_entry(h), k
+        assert d["newcol"] == [(lib.pwo_dbg_newcol(h)[x] << 1) | lib.pwo_dbg_newins(h)[x] for x in range(L)], k
+    # (2) speculative batches, optionally across the wrap of the launch counter behind the mailbox tags
+    if fill_epoch is not None:
+        g.set_option("fill_epoch", fill_epoch)
+    g.realign_rows(n_single, n_batched)
+    for k in range(n_single, n_single + n_batched):
+        assert lib.pwo_realign_row(h, k) == 0
+    lib.pwo_compact(h)
+    assert g.dims() == (T, lib.pwo_width(h))
+    for k in list(range(n_single + n_batched)) + list(others):
+        assert g.debug_row_columns(k) == oracle.row_columns(h, k), k
+    st = g.stats()
+    assert st["cells_reference"] == lib.pwo_cells(h)
+    assert st["rows_committed"] == sum(1 for k in range(n_single + n_batched) if lib.pwo_row_length(h, k) > 0)
+    assert g.total_score() == lib.pwo_total_score(h)            # recount of every column's tallies, PW:864-892
+    lib.pwo_destroy(h)
+    g.close()
+
+
+def test_config2_tree_default_prefix_of_round_one(oracle):
+    """BASELINE.json configs[1]: the benchmark MSA itself."""
+    _prefix_parity("tree_default", 24, 136, oracle, others=(500, 5000, 13509))
+
+
+def test_config3_distributed_stress_prefix_and_epoch_wrap(oracle):
+    """BASELINE.json configs[2]; one round of it is more than 2^15 batches, so the 15-bit launch counter of
+    k_fill_v3's mailbox tags wraps inside a round: start it just below the wrap."""
+    _prefix_parity("distributed_stress", 8, 112, oracle, fill_epoch=(1 << 15) - 30, others=(20000, 40194))
+
+
+def test_config4_window_sections_of_a_realigned_msa(oracle):
+    """BASELINE.json configs[3] at a size the oracle can follow: Window.py boundaries (parts = 6) of a realigned MSA,
+    the six sections realigned side by side on the GPU, each equal to the oracle on the same section."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    from repeatresolver_amd.sharding import realign_sections
+    from repeatresolver_amd.window import merge_sections, slice_sections, window_boundaries
+    from test_window_sharding import _oracle_worker
+    cfg = dg.SimConfig(kind="Tree", copies=12, coverage=15, difference=0.01, repeat_len=6000, flank=2000,
+                       length_scale=0.3, min_aligned=300, seed=21)
+    rows = [bytes(r) for r in dg.make_msa(cfg)]
+    g = PWReAligner(rows, bandwidth=1000)
+    g.trim_ends()
+    g.realign_round()
+    real = g.export_rows()
+    g.close()
+    h = oracle.create(rows, 1000)
+    oracle.lib.pwo_trim(h)
+    oracle.lib.pwo_realign_round(h)
+    oracle.lib.pwo_total_score(h)                      # compacts, as the reference does before it writes (PW:1741)
+    assert real == oracle.export(h)
+    oracle.lib.pwo_destroy(h)
+    bounds = window_boundaries(real, parts=6)          # Window.py:41-60
+    assert len(bounds) == 7 and bounds == sorted(bounds) and bounds[0] > 0 and bounds[-1] < len(real[0])
+    secs = slice_sections(real, bounds)
+    got = realign_sections(secs, bandwidth=1000, max_rounds=1, concurrent=6)
+    for p, sec in enumerate(secs):
+        exp, _ = _oracle_worker(sec, 1000, 0, 1)
+        assert got[p] == exp, p
+    merged = merge_sections(got)
+    assert len(merged) == len(rows) and all(len(r) == len(merged[0]) for r in merged)
+
+
+def test_config5_transposon_like_to_convergence(tmp_path):
+    """BASELINE.json configs[4] stand-in (the Drosophila files are not available offline): a transposon-sized MSA run
+    to convergence through the drop-in CLI.  Expected score lines and output digest were produced by the compiled,
+    unmodified reference on the same input (oracle/gen_golden.py --transposon; 7 rounds, minutes of CPU)."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import run_file
+    with open(os.path.join(GOLDEN, "transposon_like.json")) as f:
+        fx = json.load(f)
+    ip, op = str(tmp_path / "in.msa"), str(tmp_path / "out.msa")
+    dg.write_msa(ip, dg.make_msa("transposon_like"))
+    assert hashlib.sha256(open(ip, "rb").read()).hexdigest() == fx["input_sha256"], "the seeded generator drifted"
+    rc, lines = run_file(ip, op, bandwidth=fx["bandwidth"])
+    assert rc == fx["exit_code"]
+    assert [l for l in lines if l.startswith(("OverallScore", "Rows ", "bandwidth"))] == fx["stdout"]
+    assert hashlib.sha256(open(op, "rb").read()).hexdigest() == fx["output_sha256"]
