@@ -43,7 +43,16 @@ struct Hdr {                       // lives in device memory, one per context
     unsigned long long cells_reference;
     unsigned long long rows_changed;   // commits that changed at least one column
     unsigned long long fail_reason[4]; // why speculative jobs were rejected: 0 ends/length, 1 left clamp, 2 right clamp, 3 newer column
+    unsigned long long batches, rows_committed, rows_recomputed;   // speculative batches with work; realignments committed / thrown away
     int agree, pad0;               // the two order buffers hold the same ordinals for the columns [0, agree)
+    // the k loop (PW:1695) is sequenced on the device: a batch realigns the rows rowids[next_row ...], its commit kernel moves
+    // next_row on and sizes the next batch, so the host enqueues batches without waiting for their outcome
+    int next_row, row_end;         // rows [next_row, row_end) of the current slab are still to do
+    int nb;                        // rows the next batch gathers (the first is certain to commit, the others are speculative)
+    int need_grow;                 // a commit found the column arrays too small: nothing happens until the host has regrown them
+    int window, pad1;
+    float ema;                     // running mean of rows committed per batch
+    int pad2;
 };
 
 struct Tally {                     // 32 B per column slot
@@ -52,7 +61,7 @@ struct Tally {                     // 32 B per column slot
     uint32_t pad;
 };
 
-struct JobMeta {                   // 64 B
+struct JobMeta {                   // 80 B
     int k, L, lo, hi, W, entry, ok, nnew;
     unsigned maxS;
     int ver;                       // hdr->version when the job's inputs were gathered
@@ -61,6 +70,7 @@ struct JobMeta {                   // 64 B
     unsigned clk, rclk;            // fill kernel duration in shader clocks / 100 MHz ticks (diagnostic)
     int rounds;                    // lock-step rounds the fill needed (diagnostic)
     int abort;                     // k_fill_v3: a wave gave up waiting; its siblings leave too
+    int active, pad;               // 0: the job slot is unused in this batch (everything else is left from the last use)
 };
 
 struct DState {
@@ -211,12 +221,18 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     __shared__ unsigned sh[GATHER_NT / 64];
     __shared__ unsigned s_cov[GATHER_NT + 1];
     const int job = blockIdx.x, tid = threadIdx.x;
-    const int k = jobrows[job];
     JobMeta *m = &jb.meta[job];
+    const Hdr *hd = st.hdr;
+    const int kk = hd->next_row + job;
+    if (hd->status != 0 || hd->need_grow || job >= hd->nb || kk >= hd->row_end) {      // no such job in this batch
+        if (tid == 0) m->active = 0;
+        return;
+    }
+    const int k = jobrows[kk];
     const int L = st.rowlen[k];
     const int W = st.hdr->W;
     if (L == 0) {
-        if (tid == 0) { m->k = k; m->L = 0; m->ok = 1; m->W = W; m->nnew = 0; m->cells = 0; m->ver = st.hdr->version; }
+        if (tid == 0) { m->k = k; m->L = 0; m->ok = 1; m->W = W; m->nnew = 0; m->cells = 0; m->ver = st.hdr->version; m->active = 1; }
         return;
     }
     const long long off = st.rowoff[k];
@@ -334,7 +350,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         unsigned long long U = 0;
         for (int w = 0; w < GATHER_NT / 64; ++w) U += s_u[w];
         const unsigned long long bound = U + (unsigned long long)mx * (unsigned long long)(2 * B + 4096);
-        m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx; m->abort = 0;
+        m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx; m->abort = 0; m->active = 1;
         unsigned long long cs = 0;
         for (int w = 0; w < GATHER_NT / 64; ++w) cs += s_cells[w];
         m->cells = cs; m->ver = st.hdr->version; m->slot_lo = order[lo]; m->slot_hi = order[hi];
@@ -418,7 +434,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     const int wave = UNI(tid >> 6);
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (L <= 0 || !m->ok) return;
+    if (!m->active || L <= 0 || !m->ok) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
     for (int i = tid; i < 2 * (MBDUMP + NW * 64); i += NW * 64) mbQ[i] = 0;
     for (int i = tid; i < PTDUMP + NW * 64; i += NW * 64) ptQ[i] = 0;
@@ -866,7 +882,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     if (job >= jb.njobs_launched) return;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (L <= 0 || !m->ok) return;
+    if (!m->active || L <= 0 || !m->ok) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x < V4_RB) { rP[threadIdx.x] = 0; rM[threadIdx.x] = 0; rT[threadIdx.x] = 0; }
     if (threadIdx.x == 0) { wprog = 0; wdone = 0; }
@@ -1120,10 +1136,11 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 #undef V4_SCAN_STEP
 #undef V4_FENCE
                         if (bP && __builtin_expect(UNI(TAGOF(fM)) != tagx, 0)) {
-                            // not there yet: wait for the fetcher to deliver it (bounded by a time-out that flags the job)
+                            // not there yet: wait for the fetcher to deliver it (bounded by a time-out that flags the job; once it
+                            // is flagged the remaining rows of the group run through without waiting)
                             DG_T0()
                             const unsigned t0 = V3_TICKS();
-                            for (unsigned spin = 1;; ++spin) {
+                            for (unsigned spin = 1; !dead; ++spin) {
                                 fM = LLD(ringM[r]);
                                 __builtin_amdgcn_sched_barrier(0);
                                 fP = __hip_atomic_load((const unsigned *)&ringP[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1154,6 +1171,8 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     };
                     int r_end = r_beg + nrun;
                     DG_T2()
+                    // (code size matters: with a straight-line copy per role AND per entry row the kernel outgrew the instruction
+                    // cache and every row became 30 % slower -- measured; so three whole-group copies and one loop)
                     if (cls == 0) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, PWR_INTERIOR_CLS>{});
@@ -1228,10 +1247,24 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             ran_prev = 0;
             continue;
         }
-        if (ms > ms_hi) {                                   // no work for this wave in row x
+        if (ms > ms_hi) {
+            // No work for this wave in row x: the band has not reached its macro-strip yet.  Skip to the first row of this
+            // 64-row block whose band end lies beyond the strip's first column (or to the next block) in one step -- with
+            // more macro-strips than the band is wide (NW * MS > B + MS) a wave spends whole laps here.
+            const int y0s = lo + ms * MS;
+            const unsigned long long wm = __builtin_amdgcn_ballot_w64(min((int)(dca & 0xffffffu) + B, W) > y0s) >> (x & 63);
+            const int xn = min(wm ? x + __builtin_ctzll(wm) : ((x >> 6) + 1) << 6, L);     // (> x: row x itself has no work)
+            const int al = __builtin_amdgcn_readlane((int)dca, (xn - 1) & 63) & 0xffffff;  // row xn - 1 is in this block
+            DG_INC(dg_nowork, xn - x)
+            a_prev = al; Bx_prev = min(B, W - al);
+            x = xn;
             ran_prev = 0;
-            DG_INC(dg_nowork, 1)
-            V4_NEXT_ROW()
+            if (lane == 0) LST(wprog, x);
+            if (x < L) {
+                if ((x >> 6) != blk) V4_ROTATE_BLOCK()
+                a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+                sx = __builtin_amdgcn_readlane(scur, x & 63);
+            }
             continue;
         }
         const int y0 = lo + ms * MS;
@@ -1368,7 +1401,7 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
     const int job = blockIdx.x, lane = threadIdx.x;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (L <= 0 || !m->ok) return;
+    if (!m->active || L <= 0 || !m->ok) return;
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -1535,7 +1568,7 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
     const unsigned ttag = jb.trace_tag;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (L <= 0 || !m->ok) return;
+    if (!m->active || L <= 0 || !m->ok) return;
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -1961,24 +1994,61 @@ __device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsig
     return ok;
 }
 
-// Commit the jobs of a batch in row order; stop at the first one whose inputs have changed.
-__global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs jb, int njobs)
+// Commit the jobs of a batch in row order; stop at the first one whose inputs have changed.  Then move the row pointer on
+// and size the next batch: a batch costs as long as its longest fill, and rows that overlap the rows before them are almost
+// always invalidated while the MSA is still moving, so speculate just past the running mean of rows committed per batch --
+// and never let a speculative row make the batch longer than its first row, the only one that is certain to commit (a fill
+// takes time proportional to the row's length).
+__global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs jb, int njobs, const int *rowids)
 {
     __shared__ unsigned sh[COMMIT_NT / 64];
     __shared__ int s_i[8];
     Hdr *h = st.hdr;
     if (threadIdx.x == 0) { h->ncommitted = 0; h->stop = 0; }
     __syncthreads();
-    if (h->status != 0) return;
+    if (h->status != 0 || h->need_grow) return;
+    int done = 0, live_done = 0, live_all = 0;
+    bool stopped = false;
     for (int j = 0; j < njobs; ++j) {
         JobMeta *m = &jb.meta[j];
+        if (!m->active) break;                                                    // the batch ends here
         if (m->L > 0) {
-            if (!m->ok) break;                                                    // status already set
-            if (!validate_job(st, jb, j, sh, s_i)) { if (threadIdx.x == 0) h->stop = 1; break; }
+            live_all += 1;
+            if (stopped) continue;
+            if (!m->ok) { stopped = true; continue; }                             // status already set
+            // room for the columns this commit may open?  (host regrows the arrays and the batch is repeated)
+            if ((long long)h->W + m->L + 64 > st.colcap || (long long)h->nslots + m->L + 64 > st.slotcap) {
+                if (threadIdx.x == 0) h->need_grow = 1;
+                stopped = true;
+                continue;
+            }
+            if (!validate_job(st, jb, j, sh, s_i)) { if (threadIdx.x == 0) h->stop = 1; stopped = true; continue; }
             commit_job(st, jb, j, sh, s_i);
-        }
-        if (threadIdx.x == 0) h->ncommitted = j + 1;
+            live_done += 1;
+        } else if (stopped) continue;
+        done = j + 1;
         __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        h->ncommitted = done;
+        h->next_row += done;
+        if (live_all > 0) h->batches += 1;
+        h->rows_committed += (unsigned long long)live_done;
+        h->rows_recomputed += (unsigned long long)(live_all - live_done);
+        if (h->status == 0 && !h->need_grow && done > 0) {
+            const float ema = 0.75f * h->ema + 0.25f * (float)done;
+            h->ema = ema;
+            const int k = h->next_row, left = h->row_end - k;
+            int nb = (int)(ema + 2.6f);
+            nb = max(1, min(nb, min(h->window, left)));
+            if (left > 0) {
+                const int l0 = st.rowlen[rowids[k]];
+                for (int j = 1; j < nb; ++j)
+                    if (st.rowlen[rowids[k + j]] > l0 + l0 / 16 + 64) { nb = j; break; }
+            }
+            h->nb = nb;
+        }
     }
 }
 
@@ -2056,8 +2126,6 @@ struct pwr_ctx {
     std::vector<int> rowlen;
     long long sumL = 0;
     int Lmax = 0;
-    int W_ub = 0;                         // host upper bound of the device width
-    int nslots_ub = 0;
     // options
     int window = 8;
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
@@ -2073,6 +2141,8 @@ struct pwr_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     void *h_hdr = nullptr;                // pinned staging buffer for the device header
+    void *h_ring = nullptr;               // pinned copies of the header, one per batch in flight
+    hipEvent_t ring_ev[8] = {};
     // all device allocations, for cleanup
     std::vector<void *> allocs;
 };
@@ -2140,6 +2210,10 @@ static void free_device(pwr_ctx *c)
     c->ev_used = 0;
     if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
     if (c->h_hdr) { (void)hipHostFree(c->h_hdr); c->h_hdr = nullptr; }
+    if (c->h_ring) {
+        (void)hipHostFree(c->h_ring); c->h_ring = nullptr;
+        for (auto &e : c->ring_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    }
     c->on_device = false;
 }
 
@@ -2354,7 +2428,6 @@ static int upload(pwr_ctx *c)
     }
     HIPC(hipStreamCreate(&c->stream));
     if ((rc = alloc_jobs(c, std::max(1, c->window)))) return rc;
-    c->W_ub = W; c->nslots_ub = W;
     c->on_device = true;
     std::vector<unsigned char>().swap(c->text);
     c->W_host = 0;
@@ -2389,18 +2462,14 @@ static int regrow(pwr_ctx *c, T **p, size_t keep, size_t ncap)
     return PWR_OK;
 }
 
-// Make sure the next `rows_ahead` commits (each adds at most Lmax columns / slots) fit.
-static int ensure_capacity(pwr_ctx *c, long long growth)
+// A commit found the column arrays too small (Hdr::need_grow): make room for at least `growth` more columns.  The stream
+// is idle when this runs.
+static int grow_state(pwr_ctx *c, long long growth)
 {
-    if ((long long)c->W_ub + growth + 64 <= c->st.colcap && (long long)c->nslots_ub + growth + 64 <= c->st.slotcap)
-        return PWR_OK;
     Hdr h;
     int rc = read_hdr(c, &h);
     if (rc) return rc;
     if (h.status) return h.status;
-    c->W_ub = h.W; c->nslots_ub = h.nslots;
-    if ((long long)h.W + growth + 64 <= c->st.colcap && (long long)h.nslots + growth + 64 <= c->st.slotcap)
-        return PWR_OK;
     DState &st = c->st;
     const size_t ncap = (size_t)std::max<long long>(2LL * st.colcap, (long long)std::max(h.W, h.nslots) + 2 * growth + 8192);
     const size_t ocol = st.colcap, oslot = st.slotcap;
@@ -2415,7 +2484,10 @@ static int ensure_capacity(pwr_ctx *c, long long growth)
     st.colcap = (int)ncap; st.slotcap = (int)ncap;
     const int nj = c->njobs;
     free_jobs(c);
-    return alloc_jobs(c, nj);
+    if ((rc = alloc_jobs(c, nj))) return rc;
+    const int zero = 0;
+    HIPC(hipMemcpy(&st.hdr->need_grow, &zero, sizeof(int), hipMemcpyHostToDevice));
+    return PWR_OK;
 }
 
 static int launch_fill(pwr_ctx *c, int njobs)
@@ -2486,32 +2558,34 @@ static int ensure_device(pwr_ctx *c)
     return PWR_OK;
 }
 
+static void stats_from_hdr(pwr_ctx *c, const Hdr &h)
+{
+    c->stats.cells_computed = h.cells_computed;
+    c->stats.cells_reference = h.cells_reference;
+    c->stats.rows_changed = h.rows_changed;
+    c->stats.batches = h.batches;
+    c->stats.rows_committed = h.rows_committed;
+    c->stats.rows_recomputed = h.rows_recomputed;
+    for (int i = 0; i < 4; ++i) c->stats.reject_reason[i] = h.fail_reason[i];
+}
+
 static int check_status(pwr_ctx *c)
 {
     Hdr h;
     int rc = read_hdr(c, &h);
     if (rc) return rc;
-    c->W_ub = h.W; c->nslots_ub = h.nslots;
-    c->stats.cells_computed = h.cells_computed;
-    c->stats.cells_reference = h.cells_reference;
-    c->stats.rows_changed = h.rows_changed;
-    for (int i = 0; i < 4; ++i) c->stats.reject_reason[i] = h.fail_reason[i];
+    stats_from_hdr(c, h);
     return h.status;
 }
 
-// One speculative batch: rows k0 .. k0+n-1 are gathered from the committed state, filled and traced
-// side by side (one work-group each), then committed in row order by one work-group that stops at
-// the first row whose inputs an earlier commit of this batch has changed.  *done = rows finished.
-static int run_batch(pwr_ctx *c, int k0, int n, int *done)
+// One speculative batch, enqueued without waiting: the rows rowids[next_row ...] (Hdr, at most `window` of them) are
+// gathered from the committed state, filled and traced side by side, then committed in row order by one work-group that stops
+// at the first row whose inputs an earlier commit of this batch has changed, moves next_row on and sizes the next batch.
+static int enqueue_batch(pwr_ctx *c)
 {
-    long long growth = 0;
-    int live = 0;
-    for (int k = k0; k < k0 + n; ++k) { growth += c->rowlen[k]; live += c->rowlen[k] > 0; }
-    *done = n;
-    if (live == 0) return PWR_OK;                                              // PW:1488 rows without bases
-    int rc = ensure_capacity(c, growth);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_gather, dim3(n), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids + k0);
+    const int n = c->window;
+    int rc;
+    hipLaunchKernelGGL(k_gather, dim3(n), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids);
     if ((rc = launch_fill(c, n))) return rc;
     if (c->par_trace) {
         if (++c->trace_epoch >= (1u << 22)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * 16 * 8, c->stream)); c->trace_epoch = 1; }
@@ -2519,20 +2593,71 @@ static int run_batch(pwr_ctx *c, int k0, int n, int *done)
         hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
     }
     else hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
-    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n);
+    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n, c->d_rowids);
     HIPC(hipGetLastError());
+    return PWR_OK;
+}
+
+#define PWR_INFLIGHT 3             // batches enqueued beyond the last one whose outcome the host has seen
+
+// Rows k0 .. k0+n-1 in input order (a slab of the k loop, PW:1695-1737), speculative batches inside the slab only.  The
+// device sequences the rows itself (Hdr::next_row); the host keeps PWR_INFLIGHT batches queued and looks at a copy of the
+// header that trails by that many batches, so no launch waits for a round trip.  Batches enqueued after the slab's last row
+// was committed find nothing to do.
+static int realign_range(pwr_ctx *c, int k0, int n)
+{
+    if (!c->h_ring) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, sizeof(Hdr) * PWR_INFLIGHT, hipHostMallocDefault) != hipSuccess) return PWR_ERR_NOMEM;
+        c->h_ring = p;
+        for (int i = 0; i < PWR_INFLIGHT; ++i) HIPC(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
+    }
+    Hdr *ring = static_cast<Hdr *>(c->h_ring);
+    const int kend = k0 + n;
+    {
+        // start the slab: rows [k0, kend), first batch sized like the host did before (the running mean carries over)
+        int nb = (int)(c->batch_ema + 2.6);
+        nb = std::max(1, std::min(nb, std::min(c->window, n)));
+        for (int j = 1; j < nb; ++j)
+            if (c->rowlen[k0 + j] > c->rowlen[k0] + c->rowlen[k0] / 16 + 64) { nb = j; break; }
+        struct { int next_row, row_end, nb, need_grow, window, pad1; float ema; int pad2; } init = {k0, kend, nb, 0, c->window, 0, (float)c->batch_ema, 0};
+        static_assert(sizeof(init) == sizeof(Hdr) - offsetof(Hdr, next_row), "slab fields of Hdr");
+        HIPC(hipMemcpyAsync(&c->st.hdr->next_row, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        HIPC(hipStreamSynchronize(c->stream));                                 // (init lives on the stack)
+    }
+    int rc;
+    long long issued = 0, looked = 0;                                          // batches enqueued / batches whose outcome the host has seen
+    const long long most = n;                                                  // every batch with rows left commits at least one
+    while (true) {
+        while (issued < most && issued - looked < PWR_INFLIGHT) {
+            if ((rc = enqueue_batch(c))) return rc;
+            const int slot = (int)(issued % PWR_INFLIGHT);
+            HIPC(hipMemcpyAsync(&ring[slot], c->st.hdr, sizeof(Hdr), hipMemcpyDeviceToHost, c->stream));
+            HIPC(hipEventRecord(c->ring_ev[slot], c->stream));
+            ++issued;
+        }
+        if (looked == issued) { (void)hipStreamSynchronize(c->stream); return PWR_ERR_INTERNAL; }   // rows left although every batch commits one: cannot happen
+        const int slot = (int)(looked % PWR_INFLIGHT);
+        HIPC(hipEventSynchronize(c->ring_ev[slot]));
+        const Hdr h = ring[slot];
+        ++looked;
+        if (h.status) { (void)hipStreamSynchronize(c->stream); return h.status; }
+        if (h.need_grow) {
+            // the batches queued behind this one do nothing while the flag is up
+            HIPC(hipStreamSynchronize(c->stream));
+            long long growth = 0;
+            for (int j = 0; j < c->window && h.next_row + j < kend; ++j) growth += c->rowlen[h.next_row + j];
+            if ((rc = grow_state(c, growth))) return rc;
+            return realign_range(c, h.next_row, kend - h.next_row);
+        }
+        if (h.next_row >= kend) break;
+    }
+    HIPC(hipStreamSynchronize(c->stream));                                     // the no-op batches behind the last real one
     Hdr h;
     if ((rc = read_hdr(c, &h))) return rc;
-    c->W_ub = h.W; c->nslots_ub = h.nslots;
-    if (h.status) return h.status;
-    if (h.ncommitted < 1) return PWR_ERR_INTERNAL;                             // the first job is always exact
-    *done = h.ncommitted;
-    c->stats.batches += 1;
-    for (int k = k0; k < k0 + n; ++k) {
-        if (c->rowlen[k] == 0) continue;
-        if (k < k0 + h.ncommitted) c->stats.rows_committed += 1; else c->stats.rows_recomputed += 1;
-    }
-    return rc;
+    c->batch_ema = h.ema;
+    stats_from_hdr(c, h);
+    return h.status;
 }
 
 extern "C" int pwr_realign_row(pwr_ctx *c, int k)
@@ -2540,34 +2665,7 @@ extern "C" int pwr_realign_row(pwr_ctx *c, int k)
     if (!c || k < 0 || k >= c->T) return PWR_ERR_ARG;
     int rc = ensure_device(c);
     if (rc) return rc;
-    int done = 0;
-    if ((rc = run_batch(c, k, 1, &done))) return rc;
-    return check_status(c);
-}
-
-// Rows k0 .. k0+n-1 in input order (a slab of the k loop, PW:1695-1737), speculative batches inside the slab only.
-static int realign_range(pwr_ctx *c, int k0, int n)
-{
-    int k = k0;
-    const int kend = k0 + n;
-    double ema = c->batch_ema;
-    int rc;
-    while (k < kend) {
-        // A batch costs as long as its longest fill; rows that overlap the rows before them are almost
-        // always invalidated while the MSA is still moving, so speculate just past the running mean.
-        int nb = (int)(ema + 2.6);
-        nb = std::max(1, std::min(nb, std::min(c->window, kend - k)));
-        // ... and never let a speculative row make the batch longer than its first row, the only one
-        // that is certain to commit: a fill takes time proportional to the row's length
-        for (int j = 1; j < nb; ++j)
-            if (c->rowlen[k + j] > c->rowlen[k] + c->rowlen[k] / 16 + 64) { nb = j; break; }
-        int done = 0;
-        if ((rc = run_batch(c, k, nb, &done))) return rc;
-        ema = 0.75 * ema + 0.25 * done;
-        k += done;
-    }
-    c->batch_ema = ema;
-    return check_status(c);
+    return realign_range(c, k, 1);
 }
 
 extern "C" int pwr_realign_rows(pwr_ctx *c, int k0, int n)
@@ -2727,7 +2825,7 @@ extern "C" int pwr_reset_stats(pwr_ctx *c)
     if (c->on_device) {
         if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
         HIPC(hipStreamSynchronize(c->stream));
-        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 7 * sizeof(unsigned long long)));
+        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 10 * sizeof(unsigned long long)));
     }
     return PWR_OK;
 }

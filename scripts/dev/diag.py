@@ -7,9 +7,10 @@ _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), "libpwr_diag.so")
 from repeatresolver_amd import datagen as dg
 from repeatresolver_amd.realigner import PWReAligner
 wl = sys.argv[1] if len(sys.argv) > 1 else "tree_medium"
+waves = int(os.environ.get("WAVES", "9"))
 ks = [int(v) for v in sys.argv[2:]] or [0, 1, 2]
 rows = [bytes(r) for r in dg.make_msa(wl)]
-g = PWReAligner(rows, bandwidth=1000, window=1)
+g = PWReAligner(rows, bandwidth=1000, window=1, waves=waves)
 g.trim_ends(); g.total_score()
 lib = _lib.load()
 lib.pwr_debug_fill_diag.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]
@@ -20,8 +21,8 @@ for k in ks:
     lib.pwr_debug_fill_diag(g._h, buf)
     L = buf[7]
     print(f"row {k}: L={L} fill {us:.1f} us = {1e3*us/max(L,1):.1f} ns/DP row, clock {mhz:.0f} MHz")
-    base1 = min(buf[w*16+9] for w in range(9)); base2 = min(buf[w*16+10] for w in range(9))
-    for w in range(9):
+    base1 = min(buf[w*16+9] for w in range(waves)); base2 = min(buf[w*16+10] for w in range(waves))
+    for w in range(waves):
         d = buf[w*16:(w+1)*16]
         print(f"  wave {w}: reached row 1024 at +{(d[9]-base1)*10} ns, row 2048 at +{(d[10]-base2)*10} ns (after the first wave to get there)")
         tot = d[0]
