@@ -52,6 +52,8 @@ typedef struct pwr_stats {
     uint64_t rows_changed;      /* committed realignments that changed the MSA */
     uint64_t reject_reason[4];  /* speculative rejections: interval ends/length, left clamp, right clamp, newer column */
     uint64_t fill_launches_timed; /* launches covered by fill_ms (the first 65536 after a reset) */
+    uint64_t rows_wide;         /* committed realignments whose scores were not provably below 2^30 and that the 64-bit fill
+                                   (the reference's own arithmetic, PW:30, PW:271) computed */
 } pwr_stats;
 
 /* Replaces MMA_Einlesen (PW:93-241) for an in-memory matrix: `text` holds rows*width characters,

@@ -44,6 +44,7 @@ struct Hdr {                       // lives in device memory, one per context
     unsigned long long rows_changed;   // commits that changed at least one column
     unsigned long long fail_reason[4]; // why speculative jobs were rejected: 0 ends/length, 1 left clamp, 2 right clamp, 3 newer column
     unsigned long long batches, rows_committed, rows_recomputed;   // speculative batches with work; realignments committed / thrown away
+    unsigned long long rows_wide;      // committed realignments that were filled by k_fill64
     int agree, pad0;               // the two order buffers hold the same ordinals for the columns [0, agree)
     // the k loop (PW:1695) is sequenced on the device: a batch realigns the rows rowids[next_row ...], its commit kernel moves
     // next_row on and sizes the next batch, so the host enqueues batches without waiting for their outcome
@@ -70,7 +71,8 @@ struct JobMeta {                   // 80 B
     unsigned clk, rclk;            // fill kernel duration in shader clocks / 100 MHz ticks (diagnostic)
     int rounds;                    // lock-step rounds the fill needed (diagnostic)
     int abort;                     // k_fill_v3: a wave gave up waiting; its siblings leave too
-    int active, pad;               // 0: the job slot is unused in this batch (everything else is left from the last use)
+    int active;                    // 0: the job slot is unused in this batch (everything else is left from the last use)
+    int wide;                      // 1: the scores may not fit 32 bits: k_fill64 fills this job, the wave pipeline skips it
 };
 
 struct DState {
@@ -93,14 +95,12 @@ struct DState {
 struct JobBufs {
     JobMeta *meta;
     int *way;                      // [njobs][Lmax]   ordinal of every base (PW:31 Way)
-    uint4 *rec;                    // [njobs][colcap] DP input records of the job's column interval
     int4 *rec2;                    // [njobs][2*colcap] the same pre-combined for k_fill_v2: {S0-G,S1-G,S2-G,S3-G},{up-G,G,INF-G,0}
     uint8_t *mark;                 // [njobs][colcap] old symbol marks (base+1 / 0)
     uint8_t *mark2;                // [njobs][colcap] new symbol marks
     uint32_t *dirs;                // [njobs][dirstride] traceback record, 2 bits per DP cell
     int *newcol;                   // [njobs][Lmax]   (ordinal << 1) | opened-a-new-column
     int *aux;                      // [njobs][Lmax]   slot of every base after the commit
-    unsigned *gbase;               // [njobs][Lmax]   G(anf(x)): per-DP-row base of the prefix sums
     uint4 *desc;                   // [njobs][Lmax]   per DP row: {anf | base << 24, flags of waves 0-7, 8-15, 16-23} (4 bits per wave)
     int wpNW, wpMS;                // geometry of the wave pipeline the descriptors are made for
     unsigned *lastM;               // [njobs][NC]     scores of the last DP row (wave-pipeline fill)
@@ -109,6 +109,8 @@ struct JobBufs {
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
     unsigned long long *gtr;       // [njobs][TRK]    k_trace_par: hand-over words of the chunks
     unsigned trace_tag;            // 22-bit launch tag of those words
+    long long *g64;                // [njobs][colcap] k_fill64: 64-bit prefix sums of S(.,4)
+    int force64;                   // test hook: every job takes the 64-bit fill
     unsigned long long *diag;      // [njobs][32][16] per-wave counters of k_fill_v3 (only written when built with -DPWR_DIAG)
     int njobs_launched;
     int Lmax, colcap, NC;
@@ -246,7 +248,6 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     const int lo = max(0, a0 - 1), hi = min(W - 1, aL + B - 1);
     const int n = hi - lo + 1;
     uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
-    uint4 *rec = jb.rec + (size_t)job * jb.colcap;
     int4 *rec2 = jb.rec2 + (size_t)job * jb.colcap * 2;
     for (int i = tid; i < n; i += GATHER_NT) mark[i] = 0;
     __syncthreads();
@@ -282,7 +283,6 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         if (tid == GATHER_NT - 1) s_cov[0] = w[5];
         if (valid) {
             const unsigned upc = (y == 0 || y == W - 1) ? PWR_INF : max(w[5], covl);
-            rec[i] = make_uint4(w[0] | (w[1] << 16), w[2] | (w[3] << 16), carry + gin, upc);
             const int g = (int)(carry + gin);
             rec2[2 * i] = make_int4((int)w[0] - g, (int)w[1] - g, (int)w[2] - g, (int)w[3] - g);
             rec2[2 * i + 1] = make_int4((int)(upc == PWR_INF ? PWR_INF - 1u : upc) - g, g, (int)PWR_INF - g, 0);   // INF-1: pm + up stays below 2^31
@@ -292,13 +292,9 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         __syncthreads();
     }
     unsigned long long mycells = 0;
-    {
-        unsigned *gbase = jb.gbase + (size_t)job * jb.Lmax;
-        for (int x = tid; x < L; x += GATHER_NT) {
-            const int ax = max(0, way[x] - H);
-            gbase[x] = rec[ax - lo].z;
-            mycells += (unsigned long long)min(B, W - ax);                  // cells of DP row x, PW:1496-1499
-        }
+    for (int x = tid; x < L; x += GATHER_NT) {
+        const int ax = max(0, way[x] - H);
+        mycells += (unsigned long long)min(B, W - ax);                      // cells of DP row x, PW:1496-1499
     }
     if (jb.wpNW > 0) {
         // Row descriptors for the wave-pipeline fills: what every wave would otherwise recompute per DP row (anf < 2^24,
@@ -354,9 +350,9 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         unsigned long long cs = 0;
         for (int w = 0; w < GATHER_NT / 64; ++w) cs += s_cells[w];
         m->cells = cs; m->ver = st.hdr->version; m->slot_lo = order[lo]; m->slot_hi = order[hi];
-        // k_fill_v2 works with absolute prefix sums G: their total (= bases in the interval) must stay below 2^29
-        m->ok = (mx <= 0xffffu && bound < (unsigned long long)PWR_INF && carry < (1u << 29)) ? 1 : 0;
-        if (!m->ok) atomicCAS(&st.hdr->status, 0, PWR_ERR_RANGE);
+        // the wave pipeline works with absolute prefix sums G: their total (= bases in the interval) must stay below 2^29
+        m->ok = 1;
+        m->wide = (jb.force64 || !(bound < (unsigned long long)PWR_INF && carry < (1u << 29))) ? 1 : 0;   // -> k_fill64
     }
 }
 
@@ -406,7 +402,7 @@ __device__ __forceinline__ unsigned acc_push(unsigned acc, unsigned long long ma
     }
 
 template <int NW, int C>
-__global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
+__global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)   // (jobs flagged wide are left to k_fill64)
 {
     constexpr int MS = 64 * C, RS = NW * MS;
     // What lane 63 of a wave publishes per DP row.  Every item is one 64-bit word {value, row + 1}, stored and loaded
@@ -434,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)
     const int wave = UNI(tid >> 6);
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok) return;
+    if (!m->active || L <= 0 || !m->ok || m->wide) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
     for (int i = tid; i < 2 * (MBDUMP + NW * 64); i += NW * 64) mbQ[i] = 0;
     for (int i = tid; i < PTDUMP + NW * 64; i += NW * 64) ptQ[i] = 0;
@@ -882,7 +878,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     if (job >= jb.njobs_launched) return;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok) return;
+    if (!m->active || L <= 0 || !m->ok || m->wide) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x < V4_RB) { rP[threadIdx.x] = 0; rM[threadIdx.x] = 0; rT[threadIdx.x] = 0; }
     if (threadIdx.x == 0) { wprog = 0; wdone = 0; }
@@ -1390,6 +1386,178 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 #undef V4_FLUSH
 #undef V4_ROTATE_BLOCK
 #undef V4_NEXT_ROW
+}
+
+// ---------------------------------------------------------------------------------------------
+// fill, 64-bit fallback (the reference's own arithmetic: unsigned long Matrix, INF = ULONG_MAX/2, PW:30, PW:271).  Taken
+// per job when the gather cannot prove that the scores of the row fit the 32-bit wave pipeline (very deep stacks: the
+// bound is cost of the present placement + (2B + 4096) x the largest tally >= 2^30, or 2^29 bases in the interval).  One
+// work-group per job, two band cells per thread, tallies read straight from the state, the in-row dependency as the same
+// min-plus scan (block-wide, 64-bit); output in the layout the traceback kernels read: two bits per cell, and the last
+// row's scores RELATIVE to their minimum (the entry scan of PW:1352-1360 only compares them), saturated at 2^32 - 2.
+// Slow (two barriers per DP row) and never on the benchmark path.
+// ---------------------------------------------------------------------------------------------
+#define F64_NT 1024
+#define F64_INF (1ll << 62)
+__global__ __launch_bounds__(F64_NT) void k_fill64(DState st, JobBufs jb)
+{
+    __shared__ long long prevM[2][2 * F64_NT + 2];          // DP rows x-1 / x, band-relative
+    __shared__ long long wtot[F64_NT / 64];
+    __shared__ long long s_lastcell[2], s_min;
+    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    JobMeta *m = &jb.meta[job];
+    const int L = m->L;
+    if (!m->active || L <= 0 || !m->ok || !m->wide) return;
+    const int lo = m->lo, hi = m->hi, W = m->W, B = st.B, H = st.H, RS = jb.NC;
+    const int n = hi - lo + 1;
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const uint8_t *seq = st.seq + st.rowoff[m->k];
+    const uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
+    const int *order = cur_order(st);
+    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+    unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
+    long long *G = jb.g64 + (size_t)job * jb.colcap;          // G[i] = sum_{j <= i} S(lo + j, 4), row removed
+    const int way0 = way[0], wayL = way[L - 1];
+    // tallies of column y with the row's own symbol taken out (Columns_Downdater, PW:1172-1201)
+    auto tally_of = [&](int y, uint32_t *w) {
+        const Tally t = st.tally[order[y]];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) w[b] = t.w[b];
+        if (y >= way0 && y <= wayL) {
+            const int mk = mark[y - lo];
+            const int own = mk ? mk - 1 : 4;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) w[b] -= (b != own) ? 1u : 0u;
+        }
+    };
+    // ---- prefix sums of S(.,4) over the interval, traceback words cleared, last-row slots marked unused
+    {
+        long long carry = 0;
+        for (int base = 0; base < n; base += F64_NT) {
+            const int i = base + tid;
+            long long v = 0;
+            if (i < n) { uint32_t w[6]; tally_of(lo + i, w); v = (long long)w[4]; }
+            long long incl = v;
+            for (int o = 1; o < 64; o <<= 1) { const long long t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            if (lane == 63) wtot[wv] = incl;
+            __syncthreads();
+            long long pre = 0, tot = 0;
+            for (int w = 0; w < F64_NT / 64; ++w) { const long long s = wtot[w]; pre += (w < wv) ? s : 0; tot += s; }
+            __syncthreads();
+            if (i < n) G[i] = carry + pre + incl;
+            carry += tot;
+        }
+        const size_t nwords = (size_t)((L + 15) / 16) * RS;
+        for (size_t i = tid; i < nwords; i += F64_NT) dirs[i] = 0;
+        for (int i = tid; i < RS; i += F64_NT) lastM[i] = 0xffffffffu;
+        __syncthreads();
+    }
+    auto Gat = [&](int y) -> long long { return y < lo ? 0 : G[y - lo]; };      // (y >= lo - 1 always)
+    int a_prev = 0, B_prev = 0;
+    for (int x = 0; x < L; ++x) {
+        const int a = max(0, way[x] - H), Bx = min(B, W - a);                    // PW:1496-1497
+        const int sx = seq[x];
+        const long long *pv = prevM[(x & 1) ^ 1];
+        long long *cur = prevM[x & 1];
+        const long long plast = s_lastcell[(x & 1) ^ 1];                         // M[x-1][B-1], for the extension of PW:285-295
+        // Out(x-1, y), PW:249-303
+        auto out_prev = [&](int y) -> long long {
+            if (x == 0) return 0;
+            if (y < 0 || y < a_prev) return F64_INF;
+            if (y >= a_prev + B_prev) return plast >= F64_INF ? F64_INF : plast + Gat(y) - Gat(a_prev + B_prev - 1);
+            return pv[y - a_prev];
+        };
+        long long tg[2], gy[2];
+        bool cbit[2], inb[2];
+        long long run = F64_INF;                                                 // min over this thread's cells of t - G
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = 2 * tid + i, y = a + j;
+            inb[i] = j < Bx;
+            tg[i] = F64_INF; gy[i] = 0; cbit[i] = false;
+            if (inb[i]) {
+                uint32_t w[6];
+                tally_of(y, w);
+                long long d = out_prev(y - 1);
+                d = d >= F64_INF ? F64_INF : d + (long long)w[sx < 4 ? sx : 3];   // PW:1503
+                long long u = F64_INF;
+                if (y > 0 && y < W - 1) {                                         // PW:1505
+                    uint32_t wl[6];
+                    tally_of(y - 1, wl);
+                    const long long o = out_prev(y);
+                    u = o >= F64_INF ? F64_INF : o + (long long)max(w[5], wl[5]); // PW:1507
+                }
+                cbit[i] = d <= u;
+                tg[i] = min(d, u);
+                gy[i] = G[y - lo];
+                run = min(run, tg[i] >= F64_INF ? F64_INF : tg[i] - gy[i]);
+            }
+        }
+        // exclusive block prefix-min of (t - G) in band order
+        long long incl = run;
+        for (int o = 1; o < 64; o <<= 1) { const long long t = __shfl_up(incl, o); if (lane >= o) incl = min(incl, t); }
+        if (lane == 63) wtot[wv] = incl;
+        __syncthreads();
+        long long pre = F64_INF;
+        for (int w = 0; w < wv; ++w) pre = min(pre, wtot[w]);
+        long long excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = F64_INF;
+        long long p = min(pre, excl);
+        unsigned abits = 0;
+        long long Mv[2] = {F64_INF, F64_INF};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (inb[i]) {
+                const long long q = tg[i] >= F64_INF ? F64_INF : tg[i] - gy[i];
+                if (q >= p) abits |= 1u << i;                                     // PW:1375: M equals the left candidate
+                p = min(p, q);
+                Mv[i] = p >= F64_INF ? F64_INF : p + gy[i];
+            }
+        }
+        if (x == L - 1) {
+            // PW:1386: on the last row a cell that merely EQUALS its left neighbour is a (blank) left move too
+            long long leftv = __shfl_up(Mv[1], 1);
+            if (lane == 0) leftv = F64_INF;
+            // (the neighbour wave's last cell: through LDS)
+            cur[2 * tid] = Mv[0]; cur[2 * tid + 1] = Mv[1];
+            __syncthreads();
+            if (tid > 0) leftv = cur[2 * tid - 1];
+            if (inb[0] && Mv[0] == leftv) abits |= 1u;
+            if (inb[1] && Mv[1] == Mv[0]) abits |= 2u;
+        } else {
+            cur[2 * tid] = Mv[0]; cur[2 * tid + 1] = Mv[1];
+        }
+        if (2 * tid == ((Bx - 1) & ~1)) s_lastcell[x & 1] = Mv[(Bx - 1) & 1];
+        // traceback bits: word (x / 16, (y - lo) mod RS), A at bit 15 - x % 16, C at bit 31 - x % 16
+        const int sh = 15 - (x & 15);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (inb[i]) {
+                const unsigned v = (((abits >> i) & 1u) << sh) | ((cbit[i] ? 1u : 0u) << (16 + sh));
+                if (v) atomicOr(&dirs[(size_t)(x >> 4) * RS + (size_t)((a + 2 * tid + i - lo) % RS)], v);
+            }
+        }
+        a_prev = a; B_prev = Bx;
+        __syncthreads();
+    }
+    // ---- last row, relative to its minimum
+    {
+        const long long *lr = prevM[(L - 1) & 1];
+        const int a = a_prev, Bx = B_prev;
+        long long mn = F64_INF;
+        for (int j = tid; j < Bx; j += F64_NT) mn = min(mn, lr[j]);
+        for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+        if (lane == 0) wtot[wv] = mn;
+        __syncthreads();
+        if (tid == 0) { long long r = F64_INF; for (int w = 0; w < F64_NT / 64; ++w) r = min(r, wtot[w]); s_min = r; }
+        __syncthreads();
+        const long long r = s_min;
+        for (int j = tid; j < Bx; j += F64_NT) {
+            const long long v = lr[j] >= F64_INF ? (long long)0xfffffffeu : min(lr[j] - r, (long long)0xfffffffeu);
+            lastM[(a + j - lo) % RS] = (unsigned)v;
+        }
+    }
+    if (tid == 0) atomicAdd(&st.hdr->cells_computed, m->cells);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2025,6 +2193,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
             if (!validate_job(st, jb, j, sh, s_i)) { if (threadIdx.x == 0) h->stop = 1; stopped = true; continue; }
             commit_job(st, jb, j, sh, s_i);
             live_done += 1;
+            if (m->wide && threadIdx.x == 0) h->rows_wide += 1;
         } else if (stopped) continue;
         done = j + 1;
         __syncthreads();
@@ -2130,6 +2299,7 @@ struct pwr_ctx {
     int window = 8;
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
+    int force64 = 0;                      // test hook: every job takes k_fill64
     int par_trace = 1;                    // 1: speculative-parallel traceback (k_trace_par), 0: single-wave k_trace_wp
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP; cross-check and fallback)
@@ -2286,20 +2456,20 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     const int wpC = c->wp_waves == 17 ? 1 : c->wp_waves == 8 ? 3 : c->wp_waves == 5 ? 4 : c->wp_waves == 4 ? 6 : c->wp_waves == 3 ? 8 : (c->B <= 1024 ? 2 : 4);
     const int NC = c->wp_waves * 64 * wpC;
     jb.Lmax = std::max(c->Lmax, 1);
+    jb.force64 = c->force64;
     jb.colcap = c->st.colcap;
     jb.NC = NC;
     jb.dirstride = (size_t)((jb.Lmax + 15) / 16) * NC;
     int rc;
     if ((rc = dmalloc(c, &jb.meta, njobs))) return rc;
     if ((rc = dmalloc(c, &jb.way, (size_t)njobs * jb.Lmax))) return rc;
-    if ((rc = dmalloc(c, &jb.rec, (size_t)njobs * jb.colcap))) return rc;
+    if ((rc = dmalloc(c, &jb.g64, (size_t)njobs * jb.colcap))) return rc;
     if ((rc = dmalloc(c, &jb.rec2, (size_t)njobs * jb.colcap * 2))) return rc;
     if ((rc = dmalloc(c, &jb.mark, (size_t)njobs * jb.colcap))) return rc;
     if ((rc = dmalloc(c, &jb.mark2, (size_t)njobs * jb.colcap))) return rc;
     if ((rc = dmalloc(c, &jb.dirs, (size_t)njobs * jb.dirstride))) return rc;
     if ((rc = dmalloc(c, &jb.newcol, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.aux, (size_t)njobs * jb.Lmax))) return rc;
-    if ((rc = dmalloc(c, &jb.gbase, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.desc, (size_t)njobs * jb.Lmax))) return rc;
     jb.wpNW = c->wp_waves;
     jb.wpMS = 64 * wpC;
@@ -2327,8 +2497,8 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
 static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
-    dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.rec); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
-    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.gbase); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gpt); dfree(c, jb.gtr); dfree(c, jb.diag); dfree(c, c->d_jobrows);
+    dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.g64); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
+    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gpt); dfree(c, jb.gtr); dfree(c, jb.diag); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -2566,6 +2736,7 @@ static void stats_from_hdr(pwr_ctx *c, const Hdr &h)
     c->stats.batches = h.batches;
     c->stats.rows_committed = h.rows_committed;
     c->stats.rows_recomputed = h.rows_recomputed;
+    c->stats.rows_wide = h.rows_wide;
     for (int i = 0; i < 4; ++i) c->stats.reject_reason[i] = h.fail_reason[i];
 }
 
@@ -2587,6 +2758,7 @@ static int enqueue_batch(pwr_ctx *c)
     int rc;
     hipLaunchKernelGGL(k_gather, dim3(n), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids);
     if ((rc = launch_fill(c, n))) return rc;
+    hipLaunchKernelGGL(k_fill64, dim3(n), dim3(F64_NT), 0, c->stream, c->st, c->jb);       // jobs the gather flagged wide (none, normally)
     if (c->par_trace) {
         if (++c->trace_epoch >= (1u << 22)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * 16 * 8, c->stream)); c->trace_epoch = 1; }
         c->jb.trace_tag = c->trace_epoch;
@@ -2778,6 +2950,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "window")) { if (value < 1 || value > 128 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
     if (!strcmp(key, "fill")) { if (c->on_device || (value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
+    if (!strcmp(key, "force64")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->force64 = (int)value; c->jb.force64 = (int)value; return PWR_OK; }
     if (!strcmp(key, "ptrace")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
     if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }
     // (test hooks: where the launch counters behind the mailbox / hand-over tags stand, so that their wrap-around can be exercised)
@@ -2794,6 +2967,7 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "profile")) *value = c->profile;
     else if (!strcmp(key, "fill")) *value = c->fill_mode;
     else if (!strcmp(key, "ptrace")) *value = c->par_trace;
+    else if (!strcmp(key, "force64")) *value = c->force64;
     else if (!strcmp(key, "slack")) *value = c->cap_slack;
     else if (!strcmp(key, "waves")) *value = c->wp_waves;
     else return PWR_ERR_ARG;
@@ -2825,7 +2999,7 @@ extern "C" int pwr_reset_stats(pwr_ctx *c)
     if (c->on_device) {
         if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
         HIPC(hipStreamSynchronize(c->stream));
-        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 10 * sizeof(unsigned long long)));
+        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 11 * sizeof(unsigned long long)));
     }
     return PWR_OK;
 }

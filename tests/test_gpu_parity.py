@@ -37,7 +37,10 @@ def _row_by_row(name, bw, rounds, oracle, **opts):
     """Every single realignment: same Way, same entry column, same new placement, same MSA."""
     from repeatresolver_amd.realigner import PWReAligner
     rows = split_rows(golden_input(name))
+    force64 = opts.pop("force64", None)
     g = PWReAligner(rows, bandwidth=bw, **opts)
+    if force64 is not None:
+        g.set_option("force64", force64)
     g.trim_ends()
     lib = oracle.lib
     h = oracle.create(rows, bw)
@@ -64,6 +67,9 @@ def _row_by_row(name, bw, rounds, oracle, **opts):
                 lib.pwo_compact(h)
                 assert g.export_rows() == oracle.export(h), (rnd, k)
         assert g.total_score() == lib.pwo_total_score(h)
+    if force64:
+        st = g.stats()
+        assert st["rows_wide"] == st["rows_committed"] > 0
     lib.pwo_destroy(h)
     g.close()
 
@@ -104,6 +110,57 @@ def test_batched_rounds_match_sequential_oracle(window, fill, oracle):
         assert st["cells_reference"] == oracle.lib.pwo_cells(h)
         oracle.lib.pwo_destroy(h)
         g.close()
+
+
+@pytest.mark.parametrize("name,bw,rounds", STEP_CASES, ids=[c[0] for c in STEP_CASES])
+def test_force64_row_by_row(name, bw, rounds, oracle):
+    """The 64-bit fallback fill (k_fill64, PW:30 / PW:271 arithmetic) forced on ordinary inputs: every realignment against the oracle."""
+    _row_by_row(name, bw, rounds, oracle, force64=1)
+
+
+def test_wide_scores_take_the_64bit_fill(oracle):
+    """A stack so deep (180 000 rows) that the gather cannot prove the 32-bit range of the wave pipeline
+    (largest tally x (2B + 4096) > 2^30): those jobs go through k_fill64 instead of being refused.  The reference binary
+    cannot hold more than 18 000 rows (PW:17), so the checker is the CPU restatement alone."""
+    import numpy as np
+    from repeatresolver_amd.realigner import PWReAligner
+    rng = np.random.default_rng(5)
+    T, W = 180000, 36
+    tmpl = rng.integers(0, 4, W)
+    m = np.tile(tmpl, (T, 1))
+    sub = rng.random((T, W)) < 0.05
+    m[sub] = rng.integers(0, 4, int(sub.sum()))
+    txt = np.frombuffer(b"acgt", dtype=np.uint8)[m]
+    txt[rng.random((T, W)) < 0.06] = ord("-")
+    txt[:, 0] = np.frombuffer(b"acgt", dtype=np.uint8)[tmpl[0]]            # a base at both ends of every row
+    txt[:, -1] = np.frombuffer(b"acgt", dtype=np.uint8)[tmpl[-1]]
+    rows = [bytes(r) for r in txt]
+    g = PWReAligner(rows, bandwidth=1000, window=4)
+    g.trim_ends()
+    lib = oracle.lib
+    h = oracle.create(rows, 1000)
+    lib.pwo_trim(h)
+    assert g.total_score() == lib.pwo_total_score(h)
+    for k in range(6):                                   # one at a time: Way, entry, placement
+        assert lib.pwo_realign_row(h, k) == 0
+        g.realign_row(k)
+        L = lib.pwo_dbg_L(h)
+        d = g.debug_last_job()
+        assert d["L"] == L and d["entry"] == lib.pwo_dbg_entry(h), k
+        assert d["newcol"] == [(lib.pwo_dbg_newcol(h)[x] << 1) | lib.pwo_dbg_newins(h)[x] for x in range(L)], k
+    g.realign_rows(6, 30)                                # speculative batches of wide jobs
+    for k in range(6, 36):
+        assert lib.pwo_realign_row(h, k) == 0
+    lib.pwo_compact(h)
+    assert g.dims() == (T, lib.pwo_width(h))
+    for k in list(range(36)) + [T - 1]:
+        assert g.debug_row_columns(k) == oracle.row_columns(h, k), k
+    assert g.total_score() == lib.pwo_total_score(h)
+    st = g.stats()
+    assert st["cells_reference"] == lib.pwo_cells(h)
+    assert st["rows_wide"] == st["rows_committed"] == 36             # every one of them went through k_fill64
+    lib.pwo_destroy(h)
+    g.close()
 
 
 def test_launch_tag_wraparound(oracle):
