@@ -28,9 +28,10 @@ extern "C" {
 #define PWR_ERR_DEVICE (-3)      /* HIP runtime error / no usable GPU */
 #define PWR_ERR_INPUT (-4)       /* malformed MSA text (PW:121, PW:134; unequal line lengths) */
 #define PWR_ERR_RANGE (-5)       /* a limit was exceeded (row longer than 35000 bases PW:16,
-                                    bandwidth > 2000 PW:14, scores beyond the 32-bit DP range) */
+                                    bandwidth > 2000 PW:14).  Scores beyond the 32-bit range of the fast
+                                    fill are NOT an error: such rows take the 64-bit fill (pwr_stats.rows_wide) */
 #define PWR_ERR_INTERNAL (-6)    /* inconsistent traceback ("Stuff gone wrong", PW:1412-1427) */
-#define PWR_ERR_UNSUPPORTED (-7) /* state the device layout cannot hold (see pwr_create) */
+#define PWR_ERR_UNSUPPORTED (-7) /* untrimmed state: call pwr_trim_ends first (see pwr_create) */
 #define PWR_ERR_IO (-8)          /* output file cannot be opened ("DateiVerbratei!", PW:1568-1572) */
 
 #define PWR_MAX_BANDWIDTH 2000   /* PW:14 */
@@ -58,11 +59,12 @@ typedef struct pwr_stats {
 
 /* Replaces MMA_Einlesen (PW:93-241) for an in-memory matrix: `text` holds rows*width characters,
  * row-major, without newlines.  device = HIP device ordinal.  The rows are parsed and kept on the
- * host until the first device operation.  Realignment needs every row to be of the form
- * blank* (base|'-')* blank* with a base at both ends of the middle part, which is what
- * pwr_trim_ends() establishes for any input without blanks between bases and what every
- * reference-written MSAreal satisfies; other states make the device calls return
- * PWR_ERR_UNSUPPORTED. */
+ * host until the first device operation.  Realignment needs every run of non-blank cells of a row to
+ * begin and end with a base, which is what pwr_trim_ends() (EntAlGapper) establishes for ANY input and
+ * what every reference-written MSAreal satisfies -- the reference itself always trims first (PW:1655).
+ * Rows with blank runs between their bases are fine (they are kept as chains of segments until their
+ * first realignment joins them, exactly as PW:1362-1443 does).  A state that was not trimmed ('-' next to
+ * a blank or at an MSA edge) makes the device calls return PWR_ERR_UNSUPPORTED. */
 int pwr_create(pwr_ctx **out, int rows, int width, const unsigned char *text, int bandwidth, int device);
 void pwr_destroy(pwr_ctx *ctx);
 

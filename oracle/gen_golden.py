@@ -122,6 +122,19 @@ def main():
     add("edge_shift", from_rows(["acgtacgtacgtacgt--------", "----acgtacgtacgtacgt----", "--------acgtacgtacgtacgt",
                                  "acgtacgtacgtacgt--------", "--acgtacgtacgtacgtac----"]),
         ["-b", "12"], "rows offset against each other: insertions at both MSA ends")
+    # rows with blanks BETWEEN their bases: never written by the pipeline, but read by the reference (PW:165-222)
+    add("edge_inner_blanks", from_rows(["acgtacgtacgtacgtacgt", "acgt   tacgtac-tacgt", "ac-tacgt    acgtacgt", "acgtacgtacgtacgtacgt",
+                                        "  gtacg  cgta--tacg ", "acgtac-tacgtacgta   "]),
+        ["-b", "8"], "blank runs inside rows (segments), also next to '-'")
+    holes = np.frombuffer(sim(kind="Tree", copies=4, coverage=8, difference=0.01, repeat_len=1500, flank=500,
+                              length_scale=0.08, min_aligned=100, seed=23), dtype=np.uint8).copy()
+    rows_h = holes.reshape(-1, holes.tobytes().index(b"\n") + 1)
+    rng = np.random.default_rng(23)
+    for r in range(0, rows_h.shape[0], 3):                      # every third row gets one to three blank stretches
+        for _ in range(int(rng.integers(1, 4))):
+            a0 = int(rng.integers(0, rows_h.shape[1] - 60))
+            rows_h[r, a0:a0 + int(rng.integers(5, 50))] = 32
+    add("holes_b300", rows_h.tobytes(), ["-b", "300"], "simulated MSA, every third row with blank stretches inside")
     toy_b = sim(kind="Tree", copies=10, coverage=12, difference=0.01, repeat_len=4000, flank=1500,
                 length_scale=0.25, min_aligned=200, seed=12)
     add("toy_b_b1000", toy_b, [], "248 rows x 11780 columns, ~17 s of CPU")

@@ -87,6 +87,12 @@ struct DState {
     int *order0, *order1;
     int *rank;
     int *freelist;
+    // rows that came in with blanks BETWEEN their bases (never written by the pipeline, but the reference reads them,
+    // PW:165-222): such a row is a chain of segments base..base separated by blank runs until its first realignment makes
+    // it one piece (PW:1362-1443).  brkx[brkoff[k] .. + nbrk[k]) = indices of the bases after which a blank run follows.
+    const long long *brkoff;
+    const int *brkx;
+    int *nbrk;                     // [T] cleared by the row's first commit
     unsigned *colver;              // [slotcap] version of the last commit that changed the column's tallies
     int *inscnt;                   // scratch [colcap], kept all-zero between commits
     int *newidx;                   // scratch [colcap]
@@ -253,6 +259,16 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     __syncthreads();
     for (int x = tid; x < L; x += GATHER_NT) mark[way[x] - lo] = (uint8_t)(st.seq[off + x] + 1);
     __syncthreads();
+    {
+        // blank runs between the row's segments (rows read with interior blanks, until their first realignment): mark 7
+        const int nb = st.nbrk[k];
+        const int *bx = st.brkx + st.brkoff[k];
+        for (int t = tid; t < nb; t += GATHER_NT) {
+            const int b = bx[t];
+            for (int y = way[b] + 1; y < way[b + 1]; ++y) mark[y - lo] = 7;
+        }
+        if (nb) __syncthreads();
+    }
     unsigned carry = 0, maxS = 0;
     unsigned long long ucost = 0;                           // cost of the row where it stands now: an upper bound of the optimum
     if (tid == 0) s_cov[0] = 0;
@@ -267,9 +283,9 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
             for (int b = 0; b < 6; ++b) w[b] = t.w[b];
             if (y >= way0 && y <= wayL) {          // the row's own symbol: a base or '-'
                 const int mk = mark[i];
-                const int own = mk ? mk - 1 : 4;
+                const int own = mk == 7 ? 5 : (mk ? mk - 1 : 4);
 #pragma unroll
-                for (int b = 0; b < 6; ++b) w[b] -= (b != own) ? 1u : 0u;
+                for (int b = 0; b < 6; ++b) w[b] -= (own != 5 && b != own) ? 1u : 0u;
 #pragma unroll
                 for (int b = 0; b < 5; ++b) ucost += (b == own) ? w[b] : 0u;
             }
@@ -1425,9 +1441,9 @@ __global__ __launch_bounds__(F64_NT) void k_fill64(DState st, JobBufs jb)
         for (int b = 0; b < 6; ++b) w[b] = t.w[b];
         if (y >= way0 && y <= wayL) {
             const int mk = mark[y - lo];
-            const int own = mk ? mk - 1 : 4;
+            const int own = mk == 7 ? 5 : (mk ? mk - 1 : 4);
 #pragma unroll
-            for (int b = 0; b < 6; ++b) w[b] -= (b != own) ? 1u : 0u;
+            for (int b = 0; b < 6; ++b) w[b] -= (own != 5 && b != own) ? 1u : 0u;
         }
     };
     // ---- prefix sums of S(.,4) over the interval, traceback words cleared, last-row slots marked unused
@@ -1959,7 +1975,7 @@ __device__ __forceinline__ int row_symbol(const uint8_t *mk, int y, int lo, int 
 {
     if (y < y0 || y > y1) return 5;
     const int v = mk[y - lo];
-    return v ? v - 1 : 4;
+    return v == 7 ? 5 : (v ? v - 1 : 4);                  // 7: a blank run between two segments of the row
 }
 
 __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_i)
@@ -2013,8 +2029,12 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
                 const int slot = (idx < take) ? st.freelist[nfree - 1 - idx] : nslots + (idx - take);
                 const int bs = st.seq[off + x];
                 const Tally ty = st.tally[sloty];
-                const uint32_t cov = ty.w[5] - ((y >= way0 && y <= wayL) ? 1u : 0u);
-                const uint32_t ends = ty.endcnt - ((y == wayL) ? 1u : 0u);
+                // (the row itself out of both counts; between two of its segments it is blank, and a segment's last column
+                // counts as an end -- rows read with interior blanks, until this commit)
+                const bool own_nb = row_symbol(mark, y, lo, way0, wayL) != 5;
+                const bool own_end = own_nb && (y == wayL || row_symbol(mark, y + 1, lo, way0, wayL) == 5);
+                const uint32_t cov = ty.w[5] - (own_nb ? 1u : 0u);
+                const uint32_t ends = ty.endcnt - (own_end ? 1u : 0u);
                 const uint32_t al = cov - ends;                                    // PW:1305-1314
                 Tally nt;
 #pragma unroll
@@ -2057,6 +2077,14 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     if (tid == 0) {
         const int oend = order[wayL], nend = aux[L - 1];
         if (oend != nend) { st.tally[oend].endcnt -= 1; st.tally[nend].endcnt += 1; }
+    }
+    {
+        // the row is one piece from now on: its inner segment ends are no ends any more
+        const int nb = st.nbrk[k];
+        const int *bx = st.brkx + st.brkoff[k];
+        for (int t = tid; t < nb; t += COMMIT_NT) atomicSub(&st.tally[order[way[bx[t]]]].endcnt, 1u);
+        __syncthreads();
+        if (tid == 0 && nb) st.nbrk[k] = 0;
     }
     const bool restructure = (nnew > 0) || (s_i[1] != 0);
     int Wnew = W;
@@ -2256,6 +2284,13 @@ __global__ __launch_bounds__(256) void k_export(DState st, unsigned char *out, i
     for (int y = s + threadIdx.x; y <= e; y += blockDim.x) o[y] = '-';
     __syncthreads();
     for (int x = threadIdx.x; x < L; x += blockDim.x) o[st.rank[st.pos[off + x]]] = "ACGT"[st.seq[off + x]];
+    const int nb = st.nbrk[r];
+    if (nb) {
+        __syncthreads();
+        const int *bx = st.brkx + st.brkoff[r];
+        for (int t = threadIdx.x; t < nb; t += blockDim.x)
+            for (int y = st.rank[st.pos[off + bx[t]]] + 1; y < st.rank[st.pos[off + bx[t] + 1]]; ++y) o[y] = ' ';
+    }
 }
 
 // introspection (tests): ordinals of the bases of one row
@@ -2338,9 +2373,9 @@ extern "C" const char *pwr_strerror(int code)
     case PWR_ERR_NOMEM: return "out of memory";
     case PWR_ERR_DEVICE: return "HIP device error";
     case PWR_ERR_INPUT: return "malformed MSA input";
-    case PWR_ERR_RANGE: return "limit exceeded (sequence length, bandwidth or 32-bit score range)";
+    case PWR_ERR_RANGE: return "limit exceeded (sequence length or bandwidth)";
     case PWR_ERR_INTERNAL: return "inconsistent traceback";
-    case PWR_ERR_UNSUPPORTED: return "MSA state not representable on the device (untrimmed or blanks between bases)";
+    case PWR_ERR_UNSUPPORTED: return "MSA state is not trimmed ('-' next to a blank or at an edge): pwr_trim_ends first";
     case PWR_ERR_IO: return "cannot open output file";
     default: return "unknown error";
     }
@@ -2522,11 +2557,15 @@ static int upload(pwr_ctx *c)
             if (s < 4) { if (first < 0) first = i; last = i; ++L; }
             if (s != 5) for (int b = 0; b < 6; ++b) if (b != s) w[(size_t)i * 6 + b] += 1;
         }
+        // every maximal run of non-blank cells must be a segment base..base (what EntAlGapper, PW:459-645, leaves behind)
         for (int i = 0; i < W0; ++i) {
-            const int s = row[i];
-            const bool inside = first >= 0 && i >= first && i <= last;
-            if (inside ? (s == 5) : (s != 5)) return PWR_ERR_UNSUPPORTED;
+            if (row[i] == 5) continue;
+            int j = i;
+            while (j + 1 < W0 && row[j + 1] != 5) ++j;
+            if (row[i] >= 4 || row[j] >= 4) return PWR_ERR_UNSUPPORTED;
+            i = j;
         }
+        (void)first; (void)last;
         if (L > PWR_MAX_SEQ_LENGTH) return PWR_ERR_RANGE;                     // PW:675-680
         c->rowlen[r] = L;
         rowoff[r + 1] = rowoff[r] + L;
@@ -2544,14 +2583,27 @@ static int upload(pwr_ctx *c)
         if (colidx[i] >= 0) for (int b = 0; b < 6; ++b) tal[colidx[i]].w[b] = w[(size_t)i * 6 + b];
     std::vector<uint8_t> seq(std::max<long long>(c->sumL, 1));
     std::vector<int> pos(std::max<long long>(c->sumL, 1));
+    std::vector<long long> brkoff(T + 1, 0);
+    std::vector<int> brkx, nbrk(T, 0);
     for (int r = 0; r < T; ++r) {
         const unsigned char *row = &c->text[(size_t)r * W0];
         long long o = rowoff[r];
         int last = -1;
-        for (int i = 0; i < W0; ++i)
+        brkoff[r] = (long long)brkx.size();
+        for (int i = 0; i < W0; ++i) {
             if (row[i] < 4) { seq[o] = row[i]; pos[o] = colidx[i]; last = colidx[i]; ++o; }
+            else if (row[i] == 5 && last >= 0 && i > 0 && row[i - 1] != 5) {
+                // a segment ends in the column before: an inner end if more bases follow (settled below)
+                brkx.push_back((int)(o - rowoff[r]) - 1);
+            }
+        }
+        // the blank run after the row's LAST base is its margin, not a break
+        while ((long long)brkx.size() > brkoff[r] && brkx.back() == c->rowlen[r] - 1) brkx.pop_back();
+        nbrk[r] = (int)((long long)brkx.size() - brkoff[r]);
+        for (long long t = brkoff[r]; t < (long long)brkx.size(); ++t) tal[pos[rowoff[r] + brkx[t]]].endcnt += 1;
         if (last >= 0) tal[last].endcnt += 1;
     }
+    brkoff[T] = (long long)brkx.size();
     // capacities
     DState &st = c->st;
     st = DState{};
@@ -2577,6 +2629,16 @@ static int upload(pwr_ctx *c)
     if ((rc = dmalloc(c, &st.colver, st.slotcap))) return rc;
     if ((rc = dmalloc(c, &c->d_score, 1))) return rc;
     st.rowoff = d_rowoff; st.rowlen = d_rowlen; st.seq = d_seq;
+    {
+        long long *d_brkoff; int *d_brkx;
+        if ((rc = dmalloc(c, &d_brkoff, T + 1))) return rc;
+        if ((rc = dmalloc(c, &d_brkx, brkx.size()))) return rc;
+        if ((rc = dmalloc(c, &st.nbrk, T))) return rc;
+        HIPC(hipMemcpy(d_brkoff, brkoff.data(), sizeof(long long) * (T + 1), hipMemcpyHostToDevice));
+        if (!brkx.empty()) HIPC(hipMemcpy(d_brkx, brkx.data(), sizeof(int) * brkx.size(), hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(st.nbrk, nbrk.data(), sizeof(int) * T, hipMemcpyHostToDevice));
+        st.brkoff = d_brkoff; st.brkx = d_brkx;
+    }
     std::vector<int> ident(std::max(W, 1));
     for (int i = 0; i < W; ++i) ident[i] = i;
     HIPC(hipMemcpy(st.hdr, &hdr, sizeof hdr, hipMemcpyHostToDevice));
