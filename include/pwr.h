@@ -33,6 +33,9 @@ extern "C" {
 #define PWR_ERR_INTERNAL (-6)    /* inconsistent traceback ("Stuff gone wrong", PW:1412-1427) */
 #define PWR_ERR_UNSUPPORTED (-7) /* untrimmed state: call pwr_trim_ends first (see pwr_create) */
 #define PWR_ERR_IO (-8)          /* output file cannot be opened ("DateiVerbratei!", PW:1568-1572) */
+#define PWR_ERR_STALL (-9)       /* a wave of the fill kernel timed out waiting for a neighbour work-group (GPU shared or
+                                    oversubscribed) AND the geometry has no one-work-group form to repeat the job with
+                                    ("waves" = 17); with the other geometries a stall only costs time (pwr_stats.stalls) */
 
 #define PWR_MAX_BANDWIDTH 2000   /* PW:14 */
 #define PWR_MAX_SEQ_LENGTH 35000 /* PW:16 */
@@ -53,6 +56,7 @@ typedef struct pwr_stats {
     uint64_t rows_changed;      /* committed realignments that changed the MSA */
     uint64_t reject_reason[4];  /* speculative rejections: interval ends/length, left clamp, right clamp, newer column */
     uint64_t fill_launches_timed; /* launches covered by fill_ms (the first 65536 after a reset) */
+    uint64_t stalls;            /* k_fill_v3 jobs given up after a time-out and repeated by k_fill_v2 */
     uint64_t rows_wide;         /* committed realignments whose scores were not provably below 2^30 and that the 64-bit fill
                                    (the reference's own arithmetic, PW:30, PW:271) computed */
 } pwr_stats;

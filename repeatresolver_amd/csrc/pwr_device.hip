@@ -45,13 +45,15 @@ struct Hdr {                       // lives in device memory, one per context
     unsigned long long fail_reason[4]; // why speculative jobs were rejected: 0 ends/length, 1 left clamp, 2 right clamp, 3 newer column
     unsigned long long batches, rows_committed, rows_recomputed;   // speculative batches with work; realignments committed / thrown away
     unsigned long long rows_wide;      // committed realignments that were filled by k_fill64
+    unsigned long long stalls;         // k_fill_v3 jobs given up because a wave waited too long for its neighbour
     int agree, pad0;               // the two order buffers hold the same ordinals for the columns [0, agree)
     // the k loop (PW:1695) is sequenced on the device: a batch realigns the rows rowids[next_row ...], its commit kernel moves
     // next_row on and sizes the next batch, so the host enqueues batches without waiting for their outcome
     int next_row, row_end;         // rows [next_row, row_end) of the current slab are still to do
     int nb;                        // rows the next batch gathers (the first is certain to commit, the others are speculative)
     int need_grow;                 // a commit found the column arrays too small: nothing happens until the host has regrown them
-    int window, pad1;
+    int window;
+    int fallback;                  // > 0: this many batches are filled by k_fill_v2 (one work-group per job, no waiting across work-groups)
     float ema;                     // running mean of rows committed per batch
     int pad2;
 };
@@ -117,6 +119,8 @@ struct JobBufs {
     unsigned trace_tag;            // 22-bit launch tag of those words
     long long *g64;                // [njobs][colcap] k_fill64: 64-bit prefix sums of S(.,4)
     int force64;                   // test hook: every job takes the 64-bit fill
+    int gate_v2;                   // k_fill_v2 launched behind k_fill_v3: it runs only while Hdr::fallback > 0
+    int stall_test;                // test hook: job 0 of this k_fill_v3 launch pretends its neighbour never answers
     unsigned long long *diag;      // [njobs][32][16] per-wave counters of k_fill_v3 (only written when built with -DPWR_DIAG)
     int njobs_launched;
     int Lmax, colcap, NC;
@@ -446,6 +450,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)   //
     const int wave = UNI(tid >> 6);
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
+    if (jb.gate_v2 && st.hdr->fallback <= 0) return;                              // only the stand-in for k_fill_v3 here
     if (!m->active || L <= 0 || !m->ok || m->wide) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
     for (int i = tid; i < 2 * (MBDUMP + NW * 64); i += NW * 64) mbQ[i] = 0;
@@ -863,7 +868,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)   //
 #define PWR_INTERIOR_CLS 0          // (4: interior groups run the RIGHT code, experiment on the effect of equal speeds)
 #endif
 #define V3_TICKS() ((unsigned)(__builtin_amdgcn_s_memtime() >> 10))   // 32-bit time in units of 1024 shader clocks (scalar compares)
-#define V3_TIMEOUT_TICKS (1u << 23)                  // a few seconds: how long a wave waits for its neighbour before it flags the job
+#define V3_TIMEOUT_TICKS (1u << 19)                  // about 0.2 s (legitimate waits are microseconds): how long a wave waits for its neighbour before it flags the job
 #define V4_RB 128                                    // ring slots (rows); the fetcher looks at most 64 rows ahead
 
 #ifdef PWR_DIAG
@@ -894,6 +899,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     if (job >= jb.njobs_launched) return;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
+    if (st.hdr->fallback > 0) return;                                             // k_fill_v2 stands in (after a stall)
     if (!m->active || L <= 0 || !m->ok || m->wide) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x < V4_RB) { rP[threadIdx.x] = 0; rM[threadIdx.x] = 0; rT[threadIdx.x] = 0; }
@@ -1021,7 +1027,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     }
 
     DG_DECL
-    bool dead = false;
+    bool dead = jb.stall_test && job == 0 && wave == 0;                           // (test hook: as if the neighbour never answered)
     while (x < L && !dead) {
         ran_prev = UNI(ran_prev); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); ms = UNI(ms); cs = UNI(cs); gleft = UNI(gleft);
         x = UNI(x);
@@ -1382,7 +1388,10 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 #endif
     if (lane == 0) LST(wdone, 1);                                                    // releases the fetcher
     if (dead) {
-        if (lane == 0) { __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+        // A wave gave up waiting (its neighbour's work-group is not running: the GPU is shared, or more contexts are in
+        // flight than it can hold at once).  The job is flagged -- its siblings leave, trace and commit skip it -- and the
+        // commit kernel switches the next batches to k_fill_v2, which needs no other work-group (Hdr::fallback).
+        if (lane == 0) __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     if (wave == 0 && lane == 0) {
@@ -1585,7 +1594,7 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
     const int job = blockIdx.x, lane = threadIdx.x;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok) return;
+    if (!m->active || L <= 0 || !m->ok || m->abort) return;
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -1752,7 +1761,7 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
     const unsigned ttag = jb.trace_tag;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok) return;
+    if (!m->active || L <= 0 || !m->ok || m->abort) return;
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -2218,6 +2227,15 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
                 stopped = true;
                 continue;
             }
+            if (m->abort) {
+                // k_fill_v3 gave this job up (time-out): it is realigned again, by k_fill_v2, as are the next batches
+                if (threadIdx.x == 0) {
+                    h->stalls += 1;
+                    if (jb.wpNW <= 16) h->fallback = 65; else atomicCAS(&h->status, 0, PWR_ERR_STALL);   // (no one-work-group form of 17 waves)
+                }
+                stopped = true;
+                continue;
+            }
             if (!validate_job(st, jb, j, sh, s_i)) { if (threadIdx.x == 0) h->stop = 1; stopped = true; continue; }
             commit_job(st, jb, j, sh, s_i);
             live_done += 1;
@@ -2230,6 +2248,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
     if (threadIdx.x == 0) {
         h->ncommitted = done;
         h->next_row += done;
+        if (h->fallback > 0) h->fallback -= 1;
         if (live_all > 0) h->batches += 1;
         h->rows_committed += (unsigned long long)live_done;
         h->rows_recomputed += (unsigned long long)(live_all - live_done);
@@ -2335,6 +2354,7 @@ struct pwr_ctx {
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
     int force64 = 0;                      // test hook: every job takes k_fill64
+    int stall_test = 0;                   // test hook: this many k_fill_v3 launches have their first job stall
     int par_trace = 1;                    // 1: speculative-parallel traceback (k_trace_par), 0: single-wave k_trace_wp
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP; cross-check and fallback)
@@ -2377,6 +2397,7 @@ extern "C" const char *pwr_strerror(int code)
     case PWR_ERR_INTERNAL: return "inconsistent traceback";
     case PWR_ERR_UNSUPPORTED: return "MSA state is not trimmed ('-' next to a blank or at an edge): pwr_trim_ends first";
     case PWR_ERR_IO: return "cannot open output file";
+    case PWR_ERR_STALL: return "a fill kernel wave waited too long for its neighbour work-group and this geometry has no one-work-group form";
     default: return "unknown error";
     }
 }
@@ -2747,6 +2768,8 @@ static int launch_fill(pwr_ctx *c, int njobs)
         }
         c->jb.tagbase = c->fill_epoch << 17;
         c->jb.njobs_launched = njobs;
+        c->jb.stall_test = c->stall_test > 0 ? 1 : 0;
+        if (c->stall_test > 0) c->stall_test -= 1;
         const dim3 grid(8, c->wp_waves, (njobs + 7) / 8);
         if (c->wp_waves == 17) hipLaunchKernelGGL((k_fill_v3<17, 1>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4>), grid, dim3(128), 0, c->stream, c->st, c->jb);
@@ -2755,14 +2778,19 @@ static int launch_fill(pwr_ctx *c, int njobs)
         else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v3<9, 2>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_v3<9, 4>), grid, dim3(128), 0, c->stream, c->st, c->jb);
-    } else if (c->fill_mode == 3) {
+        c->jb.stall_test = 0;
+    }
+    // k_fill_v2: the fill of its own right (option fill = 3), or the stand-in behind k_fill_v3 that only runs while
+    // Hdr::fallback > 0, i.e. after a k_fill_v3 job gave up waiting for a neighbour work-group
+    c->jb.gate_v2 = c->fill_mode == 4 ? 1 : 0;
+    if (c->fill_mode == 3 || (c->fill_mode == 4 && c->wp_waves != 17)) {
         if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v2<5, 4>), dim3(njobs), dim3(5 * 64), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v2<8, 3>), dim3(njobs), dim3(8 * 64), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v2<4, 6>), dim3(njobs), dim3(4 * 64), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v2<3, 8>), dim3(njobs), dim3(3 * 64), 0, c->stream, c->st, c->jb);
         else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v2<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_v2<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
-    } else return PWR_ERR_ARG;
+    } else if (c->fill_mode != 4) return PWR_ERR_ARG;
     HIPC(hipGetLastError());
     if (timed) { HIPC(hipEventRecord(e1, c->stream)); c->stats.fill_launches_timed += 1; }
     c->stats.fill_launches += 1;
@@ -2799,6 +2827,7 @@ static void stats_from_hdr(pwr_ctx *c, const Hdr &h)
     c->stats.rows_committed = h.rows_committed;
     c->stats.rows_recomputed = h.rows_recomputed;
     c->stats.rows_wide = h.rows_wide;
+    c->stats.stalls = h.stalls;
     for (int i = 0; i < 4; ++i) c->stats.reject_reason[i] = h.fail_reason[i];
 }
 
@@ -2854,14 +2883,16 @@ static int realign_range(pwr_ctx *c, int k0, int n)
         nb = std::max(1, std::min(nb, std::min(c->window, n)));
         for (int j = 1; j < nb; ++j)
             if (c->rowlen[k0 + j] > c->rowlen[k0] + c->rowlen[k0] / 16 + 64) { nb = j; break; }
-        struct { int next_row, row_end, nb, need_grow, window, pad1; float ema; int pad2; } init = {k0, kend, nb, 0, c->window, 0, (float)c->batch_ema, 0};
-        static_assert(sizeof(init) == sizeof(Hdr) - offsetof(Hdr, next_row), "slab fields of Hdr");
+        const float ema0 = (float)c->batch_ema;
+        struct { int next_row, row_end, nb, need_grow, window; } init = {k0, kend, nb, 0, c->window};
+        static_assert(sizeof(init) == offsetof(Hdr, fallback) - offsetof(Hdr, next_row), "slab fields of Hdr");
+        HIPC(hipMemcpyAsync(&c->st.hdr->ema, &ema0, sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIPC(hipMemcpyAsync(&c->st.hdr->next_row, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
         HIPC(hipStreamSynchronize(c->stream));                                 // (init lives on the stack)
     }
     int rc;
     long long issued = 0, looked = 0;                                          // batches enqueued / batches whose outcome the host has seen
-    const long long most = n;                                                  // every batch with rows left commits at least one
+    long long most = n;                                                        // every batch with rows left commits at least one ...
     while (true) {
         while (issued < most && issued - looked < PWR_INFLIGHT) {
             if ((rc = enqueue_batch(c))) return rc;
@@ -2885,6 +2916,7 @@ static int realign_range(pwr_ctx *c, int k0, int n)
             return realign_range(c, h.next_row, kend - h.next_row);
         }
         if (h.next_row >= kend) break;
+        if (h.ncommitted == 0 && most < 2LL * n + 64) ++most;                   // ... except one whose first job stalled (it is repeated by k_fill_v2)
     }
     HIPC(hipStreamSynchronize(c->stream));                                     // the no-op batches behind the last real one
     Hdr h;
@@ -3012,6 +3044,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "window")) { if (value < 1 || value > 128 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
     if (!strcmp(key, "fill")) { if (c->on_device || (value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
+    if (!strcmp(key, "stall_test")) { if (value < 0 || value > 1000000) return PWR_ERR_ARG; c->stall_test = (int)value; return PWR_OK; }
     if (!strcmp(key, "force64")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->force64 = (int)value; c->jb.force64 = (int)value; return PWR_OK; }
     if (!strcmp(key, "ptrace")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
     if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }
@@ -3061,7 +3094,7 @@ extern "C" int pwr_reset_stats(pwr_ctx *c)
     if (c->on_device) {
         if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
         HIPC(hipStreamSynchronize(c->stream));
-        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 11 * sizeof(unsigned long long)));
+        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 12 * sizeof(unsigned long long)));
     }
     return PWR_OK;
 }

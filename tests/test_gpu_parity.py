@@ -164,6 +164,37 @@ def test_wide_scores_take_the_64bit_fill(oracle):
     g.close()
 
 
+@pytest.mark.parametrize("window", [1, 3])
+def test_stalled_fill_is_repeated_by_the_one_workgroup_kernel(window, oracle):
+    """k_fill_v3's waves wait for each other across work-groups; a wave that waits too long (GPU shared / oversubscribed)
+    gives its job up.  That must cost time only: the job and the next batches are filled by k_fill_v2 (Hdr::fallback).
+    The test hook makes the first job of the next k_fill_v3 launch stall at once (the launches behind it are gated off by
+    the fall-back, so one stall is what is seen)."""
+    from repeatresolver_amd.realigner import PWReAligner
+    name, bw = "lowcov_b300", 300
+    rows = split_rows(golden_input(name))
+    g = PWReAligner(rows, bandwidth=bw, window=window)
+    g.trim_ends()
+    g.total_score()
+    h = oracle.create(rows, bw)
+    oracle.lib.pwo_trim(h)
+    g.realign_rows(0, 5)
+    g.set_option("stall_test", 1)
+    g.realign_rows(5, len(rows) - 5)                  # one stall, then 64 batches of k_fill_v2, then k_fill_v3 again
+    oracle.lib.pwo_realign_round(h)
+    assert g.total_score() == oracle.lib.pwo_total_score(h)
+    assert g.export_rows() == oracle.export(h)
+    assert g.stats()["stalls"] == 1
+    for _ in range(3):                                # (more than 64 batches: k_fill_v3 is back)
+        g.realign_round()
+        oracle.lib.pwo_realign_round(h)
+    oracle.lib.pwo_compact(h)
+    assert g.export_rows() == oracle.export(h)
+    assert g.stats()["stalls"] == 1
+    oracle.lib.pwo_destroy(h)
+    g.close()
+
+
 def test_launch_tag_wraparound(oracle):
     """The mailbox words of k_fill_v3 and the hand-over words of k_trace_par carry a launch counter; when it wraps
     the arrays are cleared and counting restarts.  Start both counters just below their limits."""
