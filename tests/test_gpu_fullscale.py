@@ -121,3 +121,69 @@ def test_config5_transposon_like_to_convergence(tmp_path):
     assert rc == fx["exit_code"]
     assert [l for l in lines if l.startswith(("OverallScore", "Rows ", "bandwidth"))] == fx["stdout"]
     assert hashlib.sha256(open(op, "rb").read()).hexdigest() == fx["output_sha256"]
+
+
+def _hip_rank_main(rank, world, port, q):
+    """One rank of the multi-GPU path with the HIP worker (both ranks on device 0: this box has one GPU)."""
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from conftest import golden_input, split_rows
+    from repeatresolver_amd.sharding import realign_sections
+    from repeatresolver_amd.window import slice_sections
+    rows = split_rows(golden_input("toy_b_b1000"))
+    W = len(rows[0])
+    secs = slice_sections(rows, [0, W // 4, W // 2, 3 * W // 4, W])
+    out = realign_sections(secs, bandwidth=300, max_rounds=2, device=0)      # default worker: libpwr.so through the C ABI
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sections_sharded_over_two_ranks_hip_worker(oracle):
+    """The N > 1 path with the product worker under a process group: sections dealt to 2 ranks, each realigns its
+    sections on the GPU (two contexts side by side), all-gather of the text; every section equals the oracle's."""
+    import multiprocessing as mp
+    import socket
+    from conftest import golden_input, split_rows
+    from repeatresolver_amd.window import slice_sections
+    from test_window_sharding import _oracle_worker
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hip_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0] == got[1]
+    rows = split_rows(golden_input("toy_b_b1000"))
+    W = len(rows[0])
+    secs = slice_sections(rows, [0, W // 4, W // 2, 3 * W // 4, W])
+    for p, sec in enumerate(secs):
+        exp, _ = _oracle_worker(sec, 300, 0, 2)
+        assert got[0][p] == exp, p
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), rehearsed on one GPU
+    with gloo: ONE MSA cut into its Window.py sections, sections dealt to the ranks, strong scaling, per-rank times."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "tree_medium", "--backend", "gloo", "--one-device"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2
+    assert d["value"] > 0 and len(d["per_rank"]) == 2 and all(r["cells"] > 0 for r in d["per_rank"])
+    assert "sections" in d["config"]["workload"]
