@@ -121,7 +121,7 @@ struct JobBufs {
     int force64;                   // test hook: every job takes the 64-bit fill
     int gate_v2;                   // k_fill_v2 launched behind k_fill_v3: it runs only while Hdr::fallback > 0
     int stall_test;                // test hook: job 0 of this k_fill_v3 launch pretends its neighbour never answers
-    unsigned long long *diag;      // [njobs][32][16] per-wave counters of k_fill_v3 (only written when built with -DPWR_DIAG)
+    unsigned long long *diag;      // [njobs][32][128] per-wave counters and switch events of k_fill_v3 (only written when built with -DPWR_DIAG)
     int njobs_launched;
     int Lmax, colcap, NC;
     size_t dirstride;
@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 
     DG_DECL
     bool dead = jb.stall_test && job == 0 && wave == 0;                           // (test hook: as if the neighbour never answered)
+    int first_pending = 0;                                                       // row x is the wave's first on its macro-strip: the fast path takes it
     while (x < L && !dead) {
         ran_prev = UNI(ran_prev); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); ms = UNI(ms); cs = UNI(cs); gleft = UNI(gleft);
         x = UNI(x);
@@ -1042,11 +1043,14 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         // anything else (a change of role inside the group, a partial group) takes the same code with run-time flags.
         // All roles must cost about the same: a wave that is slower than its neighbour while it is the band's last strip
         // falls behind for good, and every row of lag per hop is paid NW - 1 times per lap of the ring (measured).
-        if (ran_prev && x < L - 1) {
+        if ((ran_prev || first_pending) && x < L - 1) {
             unsigned long long bOm = __builtin_amdgcn_ballot_w64((dcf & 1u) != 0);
-            if ((bOm >> (x & 63)) & 1ull) {
+            const bool first = UNI(first_pending) != 0;
+            if (first || ((bOm >> (x & 63)) & 1ull)) {
+                first_pending = 0;
                 unsigned long long bPm = __builtin_amdgcn_ballot_w64((dcf & 2u) != 0);       // needs the neighbour's running minimum
                 unsigned long long bMm = __builtin_amdgcn_ballot_w64((dcf & 4u) != 0);       // left score = neighbour's M_last(x-1)
+                if (first) { bOm |= 1ull << (x & 63); bMm |= 1ull << (x & 63); }             // (its left score is worked out below)
                 unsigned long long bTm = __builtin_amdgcn_ballot_w64((dcf & 8u) != 0);       // the band ends here: post Ptot
                 // per row of the 64-block, one lane each: anf, band end, byte offset of the row's base in the LDS table
                 int dcaf = (int)(dca & 0xffffffu), dcb = min(dcaf + B, W);
@@ -1055,7 +1059,36 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 V4_ALIGN_ACC(x & 15)
                 if (lane == 0) LST(wprog, x);                                    // the fetcher looks at the rows [x - 1, x + 63)
                 unsigned mlast_v = 0;                                            // M_last(x-1) of the left neighbour
-                if ((bMm >> (x & 63)) & 1ull) {
+                if (first) {
+                    // The wave's first row on this macro-strip (it has just taken it over, or the band has just reached it).
+                    // This is where the pipeline's critical path runs -- the band's last strip can only start when its left
+                    // neighbour delivers, and the next one waits for it in turn --, so everything that does not need the
+                    // neighbour's words of row x is done here, before them: the scores the rows above left behind are the
+                    // virtual extension G + Ptot(x-1) (PW:285-295), and the score left of the strip is the neighbour's
+                    // M_last(x-1), or that extension, or INF (PW:276).  Row x itself then runs like any other row and waits for
+                    // P_end(x) only after its scan.
+                    const unsigned tagp = tagbase | (unsigned)x;
+                    const int yq = lo + ms * MS - 1;
+                    const bool needM = yq >= a_prev && yq < a_prev + Bx_prev;
+                    unsigned long long eT = 0, eM = 0;
+                    DG_T0()
+                    const unsigned t0 = V3_TICKS();
+                    for (unsigned spin = 1;; ++spin) {
+                        eT = LLD(rT[(x - 1) & (V4_RB - 1)]);
+                        eM = LLD(rM[(x - 1) & (V4_RB - 1)]);
+                        if (UNI(TAGOF(eT)) == tagp && (!needM || UNI(TAGOF(eM)) == tagp)) break;
+                        if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    DG_ADD(dg_wait_gen)
+                    DG_INC(dg_general, 1)
+                    if (dead) break;
+                    const int eTx = (int)UNI((unsigned)eT);
+#pragma unroll
+                    for (int i = 0; i < C; ++i) Mprev[i] = (unsigned)(gg[i] + eTx);
+                    mlast_v = yq < a_prev ? PWR_INF : (needM ? UNI((unsigned)eM) : (unsigned)(gleft + eTx));
+                    ran_prev = 1;
+                } else if ((bMm >> (x & 63)) & 1ull) {
                     const unsigned tagp = tagbase | (unsigned)x;
                     unsigned long long w_ = LLD(rM[(x - 1) & (V4_RB - 1)]);
                     if (UNI(TAGOF(w_)) != tagp) {                                   // (bounded by a time-out that flags the job)
@@ -1090,11 +1123,12 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     nrun = min(nrun, L - 1 - x);
                     if (nrun <= 0) break;
                     const unsigned nPm = (unsigned)(bPm >> r0) & 0xffffu, kMm = (unsigned)(bMm >> r0) & 0xffffu, eTm = (unsigned)(bTm >> r0) & 0xffffu;
-                    int cls = 3;
-                    if (nrun == 16) {
-                        if (nPm == 0xffffu && kMm == 0xffffu) cls = eTm == 0u ? 0 : (eTm == 0xffffu ? 1 : 3);
-                        else if ((nPm | kMm | eTm) == 0u) cls = 2;
-                    }
+                    // the rows from x on that play the same role as row x: one stretch
+                    const unsigned p0 = (nPm >> r_beg) & 1u, m0 = (kMm >> r_beg) & 1u, t0_ = (eTm >> r_beg) & 1u;
+                    const unsigned diff = ((nPm ^ (0u - p0)) | (kMm ^ (0u - m0)) | (eTm ^ (0u - t0_))) & 0xffffu;
+                    const int nsame = __builtin_ctz((diff >> r_beg) | 0x10000u);
+                    const int r_e = r_beg + min(nrun, nsame);
+                    const int cls = (p0 & m0) ? (t0_ ? 1 : 0) : ((p0 | m0 | t0_) == 0u ? 2 : 3);
                     if (gacc < 0) gacc = x >> 4;
 #ifdef PWR_DIAG
                     if (!dg_ts1 && x >= 1024) dg_ts1 = __builtin_amdgcn_s_memrealtime();
@@ -1159,6 +1193,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                             DG_T0()
                             const unsigned t0 = V3_TICKS();
                             for (unsigned spin = 1; !dead; ++spin) {
+                                // (polling the neighbour's global words directly here instead was measured: no faster)
                                 fM = LLD(ringM[r]);
                                 __builtin_amdgcn_sched_barrier(0);
                                 fP = __hip_atomic_load((const unsigned *)&ringP[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1187,28 +1222,31 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                             if (bT) GST2(gpt0 + r, P_end_v, tagx);
                         }
                     };
-                    int r_end = r_beg + nrun;
+                    int r_end = r_e;
                     DG_T2()
-                    // (code size matters: with a straight-line copy per role AND per entry row the kernel outgrew the instruction
-                    // cache and every row became 30 % slower -- measured; so three whole-group copies and one loop)
-                    if (cls == 0) {
+                    // Code size matters (a straight-line copy per role and per entry row outgrew the instruction cache: every row
+                    // 30 % slower, measured), and so does straight-line code (a one-row loop body costs 1.5x per row, measured).
+                    // So: whole INTERIOR groups as 16 rows of straight-line code; everything else in blocks of 4 rows per role,
+                    // aligned to 4 -- the band's leading strip, which sets the pace of the whole pipeline, is LEFT for only ~28
+                    // rows at a time and would otherwise spend most of them in the one-row loop --, and that loop for the rest.
+                    if (cls == 0 && r_beg == 0 && r_e == 16) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, PWR_INTERIOR_CLS>{});
                         DG_INC(dg_int, 16)
                         DG_ADD2(dg_cyc_int)
-                    } else if (cls == 1) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 1>{});
-                    } else if (cls == 2) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 2>{});
                     } else {
-                        for (int r = r_beg; r < r_end; ++r) {
-                            group_row(r, std::integral_constant<int, 3>{});
-                            if (dead) { r_end = r + 1; break; }
-                        }
+                        int r = r_beg;
+                        for (; r < r_end && (r & 3) && !dead; ++r) group_row(r, std::integral_constant<int, 3>{});
+#define V4_BLOCKS(K) for (; r + 4 <= r_end && !dead; r += 4) { group_row(r, std::integral_constant<int, K>{}); group_row(r + 1, std::integral_constant<int, K>{}); \
+                                                               group_row(r + 2, std::integral_constant<int, K>{}); group_row(r + 3, std::integral_constant<int, K>{}); }
+                        if (cls == 0) V4_BLOCKS(0)
+                        else if (cls == 1) V4_BLOCKS(1)
+                        else if (cls == 2) V4_BLOCKS(2)
+#undef V4_BLOCKS
+                        for (; r < r_end && !dead; ++r) group_row(r, std::integral_constant<int, 3>{});
+                        r_end = r;
                     }
-                    if (cls != 0) { DG_INC(dg_gen16, r_end - r_beg) DG_ADD2(dg_cyc_gen16) }
+                    if (!(cls == 0 && r_beg == 0 && r_e == 16)) { DG_INC(dg_gen16, r_end - r_beg) DG_ADD2(dg_cyc_gen16) }
                     x = g0 + r_end;
                     af_done = __builtin_amdgcn_readlane(dcaf, (x - 1) & 63);       // anf of the last row done
                     if ((x & 15) == 0) {                                          // the 16-row group is complete
@@ -1285,6 +1323,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             }
             continue;
         }
+        if (!ran_prev && x > 0 && x < L - 1) { first_pending = 1; continue; }     // first row on this macro-strip: the fast path takes it
         const int y0 = lo + ms * MS;
         const int yq = y0 - 1;
         const bool needP = ms > ms_lo;
@@ -1293,6 +1332,9 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         unsigned ePx = 0, ePy = 0, eMy = 0, eTx = 0;
         {
             const unsigned tagx = tagbase | (unsigned)(x + 1), tagp = tagbase | (unsigned)x;
+#ifdef PWR_DIAG
+            const unsigned long long ev_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
             DG_T0()
             const unsigned t0 = V3_TICKS();
             for (unsigned spin = 1;; ++spin) {
@@ -1305,6 +1347,12 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
+#ifdef PWR_DIAG
+            if (lane == 0 && dg_general < 36) {
+                unsigned long long *ev = jb.diag + ((size_t)job * 32 + wave) * 128 + 16 + 3 * dg_general;
+                ev[0] = (unsigned long long)x; ev[1] = ev_t0; ev[2] = __builtin_amdgcn_s_memrealtime();
+            }
+#endif
             DG_ADD(dg_wait_gen)
             DG_INC(dg_general, 1)
             if (dead) break;
@@ -1379,7 +1427,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     V4_FLUSH()
 #ifdef PWR_DIAG
     if (lane == 0) {
-        unsigned long long *dgp = jb.diag + ((size_t)job * 32 + wave) * 16;
+        unsigned long long *dgp = jb.diag + ((size_t)job * 32 + wave) * 128;
         dgp[0] = __builtin_amdgcn_s_memtime() - t_clk0; dgp[1] = dg_wait_fast; dgp[2] = dg_wait_gen; dgp[3] = dg_wait_setup;
         dgp[4] = ((unsigned long long)dg_int << 32) | dg_gen16; dgp[5] = ((unsigned long long)dg_general << 32) | dg_nowork;
         dgp[6] = ((unsigned long long)dg_runs << 32) | dg_switch; dgp[7] = (unsigned long long)L;
@@ -2540,8 +2588,8 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
         c->fill_epoch = 0;
     }
     if ((rc = dmalloc(c, &jb.gtr, (size_t)njobs * 16))) return rc;
-    if ((rc = dmalloc(c, &jb.diag, (size_t)njobs * 32 * 16))) return rc;
-    if (hipMemsetAsync(jb.diag, 0, (size_t)njobs * 32 * 16 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
+    if ((rc = dmalloc(c, &jb.diag, (size_t)njobs * 32 * 128))) return rc;
+    if (hipMemsetAsync(jb.diag, 0, (size_t)njobs * 32 * 128 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     if (hipMemsetAsync(jb.gtr, 0, (size_t)njobs * 16 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     c->trace_epoch = 0;
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
@@ -3152,7 +3200,7 @@ extern "C" int pwr_debug_fill_diag(pwr_ctx *c, unsigned long long *out)
     if (!c || !c->on_device || !out) return PWR_ERR_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
     HIPC(hipStreamSynchronize(c->stream));
-    HIPC(hipMemcpy(out, c->jb.diag, sizeof(unsigned long long) * 32 * 16, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out, c->jb.diag, sizeof(unsigned long long) * 32 * 128, hipMemcpyDeviceToHost));
     return PWR_OK;
 }
 
