@@ -113,7 +113,6 @@ struct JobBufs {
     int wpNW, wpMS;                // geometry of the wave pipeline the descriptors are made for
     unsigned *lastM;               // [njobs][NC]     scores of the last DP row (wave-pipeline fill)
     unsigned long long *gmb;       // [njobs][NW][Lmax][2] k_fill_v3: {P_end, tag}, {M_last, tag} per wave and DP row
-    unsigned long long *gpt;       // [njobs][Lmax]   k_fill_v3: {Ptot, tag} per DP row
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
     unsigned long long *gtr;       // [njobs][TRK]    k_trace_par: hand-over words of the chunks
     unsigned trace_tag;            // 22-bit launch tag of those words
@@ -121,7 +120,7 @@ struct JobBufs {
     int force64;                   // test hook: every job takes the 64-bit fill
     int gate_v2;                   // k_fill_v2 launched behind k_fill_v3: it runs only while Hdr::fallback > 0
     int stall_test;                // test hook: job 0 of this k_fill_v3 launch pretends its neighbour never answers
-    unsigned long long *diag;      // [njobs][32][128] per-wave counters and switch events of k_fill_v3 (only written when built with -DPWR_DIAG)
+    unsigned long long *diag;      // [njobs][32][4096] per-wave counters, switch events and a progress log of k_fill_v3 (only written when built with -DPWR_DIAG)
     int njobs_launched;
     int Lmax, colcap, NC;
     size_t dirstride;
@@ -850,7 +849,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)   //
 // on the same XCD and talk through its L2.  What a wave publishes per DP row goes to global memory:
 //   gmb[(w * Lmax + x) * 2 + 0]  {P_end, tag}   the running minimum its right neighbour continues
 //   gmb[(w * Lmax + x) * 2 + 1]  {M_last, tag}  the score of its last column
-//   gpt[x]                       {Ptot, tag}    the minimum of the whole row (posted by the wave that ends the band)
+// (Ptot, the minimum of the whole row, is the P_end word of the wave that ends the band in that row.)
 // each one aligned 64-bit word, stored and loaded whole (relaxed agent-scope atomics) and self-validating:
 // tag = launch epoch << 17 | row + 1, so nothing has to be cleared between launches.  There are no rounds and
 // no barriers: a wave simply runs down its rows and waits (bounded by a time-out that flags the job) where a
@@ -872,7 +871,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)   //
 #define V4_RB 128                                    // ring slots (rows); the fetcher looks at most 64 rows ahead
 
 #ifdef PWR_DIAG
-#define DG_DECL unsigned long long dg_wait_fast = 0, dg_wait_gen = 0, dg_wait_setup = 0, dg_t = 0, dg_t2 = 0, dg_cyc_int = 0, dg_cyc_gen16 = 0, dg_ts1 = 0, dg_ts2 = 0; unsigned dg_int = 0, dg_gen16 = 0, dg_general = 0, dg_nowork = 0, dg_runs = 0, dg_switch = 0;
+#define DG_DECL unsigned long long dg_wait_fast = 0, dg_wait_gen = 0, dg_wait_setup = 0, dg_t = 0, dg_t2 = 0, dg_cyc_int = 0, dg_cyc_gen16 = 0, dg_ts1 = 0, dg_ts2 = 0; unsigned dg_log = 0; unsigned dg_int = 0, dg_gen16 = 0, dg_general = 0, dg_nowork = 0, dg_runs = 0, dg_switch = 0;
 #define DG_T0() dg_t = __builtin_amdgcn_s_memtime();
 #define DG_ADD(ACC) ACC += __builtin_amdgcn_s_memtime() - dg_t;
 #define DG_INC(CNT, N) CNT += (N);
@@ -891,7 +890,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 {
     constexpr int MS = 64 * C, RS = NW * MS;
     __shared__ __attribute__((aligned(16))) int ldsS1[2][4][MS];
-    __shared__ unsigned long long rP[V4_RB], rM[V4_RB], rT[V4_RB];      // the neighbour's {P_end, tag}, {M_last, tag}; {Ptot, tag}
+    __shared__ unsigned long long rP[V4_RB], rM[V4_RB];                  // the neighbour's {P_end, tag}, {M_last, tag}
     __shared__ int wprog, wdone;                                         // worker's progress (rows), worker finished
     const int job = blockIdx.x + 8 * blockIdx.z, lane = threadIdx.x & 63;
     const int role = UNI((int)threadIdx.x >> 6);                          // 0 worker, 1 fetcher
@@ -902,7 +901,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     if (st.hdr->fallback > 0) return;                                             // k_fill_v2 stands in (after a stall)
     if (!m->active || L <= 0 || !m->ok || m->wide) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x < V4_RB) { rP[threadIdx.x] = 0; rM[threadIdx.x] = 0; rT[threadIdx.x] = 0; }
+    if (threadIdx.x < V4_RB) { rP[threadIdx.x] = 0; rM[threadIdx.x] = 0; }
     if (threadIdx.x == 0) { wprog = 0; wdone = 0; }
     __syncthreads();
 
@@ -910,7 +909,10 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     const unsigned tagbase = jb.tagbase;
     unsigned long long *const gmy = jb.gmb + ((size_t)job * NW + wave) * (size_t)jb.Lmax * 2;
     const unsigned long long *const gleftw = jb.gmb + ((size_t)job * NW + wl) * (size_t)jb.Lmax * 2;
-    unsigned long long *const gpt = jb.gpt + (size_t)job * jb.Lmax;
+    // Ptot(r), the minimum of the whole DP row r (the virtual extension of PW:285-295 is G + Ptot): it is the P_end word of
+    // the wave that holds the band's last macro-strip in row r -- read straight from there, on the rare occasions it is needed
+    const unsigned long long *const gjob = jb.gmb + (size_t)job * NW * (size_t)jb.Lmax * 2;
+#define PTOT_PTR(AP, BP, R) (gjob + (((size_t)((((AP) + (BP) - 1 - lo) / MS) % NW)) * (size_t)jb.Lmax + (size_t)(R)) * 2)
     int *const abortf = &m->abort;
 #define GLD(PTR) __hip_atomic_load((PTR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GST(PTR, VAL, ROW) __hip_atomic_store((PTR), ((unsigned long long)(tagbase | (unsigned)((ROW) + 1)) << 32) | (unsigned)(VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -928,9 +930,9 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             const int wx = UNI(LLD(wprog));
             const int r = wx - 1 + lane;                                          // row wx needs words of row wx - 1 too
             const bool inr = r >= 0 && r < L;
-            unsigned long long p = 0, q = 0, t = 0;
+            unsigned long long p = 0, q = 0;
             int ab = 0;
-            if (inr) { p = GLD(gleftw + 2 * (size_t)r); q = GLD(gleftw + 2 * (size_t)r + 1); t = GLD(gpt + r); }
+            if (inr) { p = GLD(gleftw + 2 * (size_t)r); q = GLD(gleftw + 2 * (size_t)r + 1); }
             if ((it & 15u) == 15u) ab = GLD(abortf);
             if (inr) {
                 const unsigned tagr = tagbase | (unsigned)(r + 1);
@@ -938,7 +940,6 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     LST(rP[r & (V4_RB - 1)], p);
                     __hip_atomic_store(&rM[r & (V4_RB - 1)], q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // P before M: M's tag vouches for both
                 }
-                if (TAGOF(t) == tagr) LST(rT[r & (V4_RB - 1)], t);
             }
             // (no time-out of its own: the worker has one, and its end -- wdone -- or the job's abort flag end this loop)
             if (UNI(ab)) break;
@@ -1051,7 +1052,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 unsigned long long bPm = __builtin_amdgcn_ballot_w64((dcf & 2u) != 0);       // needs the neighbour's running minimum
                 unsigned long long bMm = __builtin_amdgcn_ballot_w64((dcf & 4u) != 0);       // left score = neighbour's M_last(x-1)
                 if (first) { bOm |= 1ull << (x & 63); bMm |= 1ull << (x & 63); }             // (its left score is worked out below)
-                unsigned long long bTm = __builtin_amdgcn_ballot_w64((dcf & 8u) != 0);       // the band ends here: post Ptot
+                unsigned long long bTm = __builtin_amdgcn_ballot_w64((dcf & 8u) != 0);       // the band ends here: guard against columns past it
                 // per row of the 64-block, one lane each: anf, band end, byte offset of the row's base in the LDS table
                 int dcaf = (int)(dca & 0xffffffu), dcb = min(dcaf + B, W);
                 unsigned dcs = min(dca >> 24, 3u) * (unsigned)(MS * 4);
@@ -1072,15 +1073,24 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     const bool needM = yq >= a_prev && yq < a_prev + Bx_prev;
                     unsigned long long eT = 0, eM = 0;
                     DG_T0()
+#ifdef PWR_DIAG
+                    const unsigned long long ev_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
                     const unsigned t0 = V3_TICKS();
                     for (unsigned spin = 1;; ++spin) {
-                        eT = LLD(rT[(x - 1) & (V4_RB - 1)]);
+                        eT = GLD(PTOT_PTR(a_prev, Bx_prev, x - 1));
                         eM = LLD(rM[(x - 1) & (V4_RB - 1)]);
                         if (UNI(TAGOF(eT)) == tagp && (!needM || UNI(TAGOF(eM)) == tagp)) break;
                         if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                     DG_ADD(dg_wait_gen)
+#ifdef PWR_DIAG
+                    if (lane == 0 && dg_general < 36) {
+                        unsigned long long *ev = jb.diag + ((size_t)job * 32 + wave) * 4096 + 16 + 3 * dg_general;
+                        ev[0] = (unsigned long long)x; ev[1] = ev_t0; ev[2] = __builtin_amdgcn_s_memrealtime();
+                    }
+#endif
                     DG_INC(dg_general, 1)
                     if (dead) break;
                     const int eTx = (int)UNI((unsigned)eT);
@@ -1125,22 +1135,25 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     const unsigned nPm = (unsigned)(bPm >> r0) & 0xffffu, kMm = (unsigned)(bMm >> r0) & 0xffffu, eTm = (unsigned)(bTm >> r0) & 0xffffu;
                     // the rows from x on that play the same role as row x: one stretch
                     const unsigned p0 = (nPm >> r_beg) & 1u, m0 = (kMm >> r_beg) & 1u, t0_ = (eTm >> r_beg) & 1u;
-                    const unsigned diff = ((nPm ^ (0u - p0)) | (kMm ^ (0u - m0)) | (eTm ^ (0u - t0_))) & 0xffffu;
+                    // (whether the band ends in the strip -- Ptot is posted -- does not split a stretch of neighbour-fed rows: the row
+                    // where the next strip's wave takes over is exactly where this wave must not dawdle)
+                    const unsigned diff = ((nPm ^ (0u - p0)) | (kMm ^ (0u - m0)) | ((p0 & m0) ? 0u : (eTm ^ (0u - t0_)))) & 0xffffu;
                     const int nsame = __builtin_ctz((diff >> r_beg) | 0x10000u);
                     const int r_e = r_beg + min(nrun, nsame);
-                    const int cls = (p0 & m0) ? (t0_ ? 1 : 0) : ((p0 | m0 | t0_) == 0u ? 2 : 3);
+                    const unsigned et_here = (eTm >> r_beg) & ((1u << (r_e - r_beg)) - 1u);
+                    const int cls = (p0 & m0) ? (et_here ? 1 : 0) : ((p0 | m0 | t0_) == 0u ? 2 : 3);
                     if (gacc < 0) gacc = x >> 4;
 #ifdef PWR_DIAG
                     if (!dg_ts1 && x >= 1024) dg_ts1 = __builtin_amdgcn_s_memrealtime();
                     if (!dg_ts2 && x >= 2048) dg_ts2 = __builtin_amdgcn_s_memrealtime();
 #endif
-                    unsigned long long *const gq0 = gmy + 2 * (size_t)g0, *const gpt0 = gpt + g0;
+                    unsigned long long *const gq0 = gmy + 2 * (size_t)g0;
                     const unsigned long long *const ringM = &rM[g0 & (V4_RB - 1)], *const ringP = &rP[g0 & (V4_RB - 1)];   // the group's 16 consecutive slots
                     auto group_row = [&](const int r, auto cls_) __attribute__((always_inline)) {
                         constexpr int CLS = decltype(cls_)::value;                 // 0 INTERIOR, 1 RIGHT, 2 LEFT, 3 run-time flags
                         const int xr = g0 + r;
-                        bool bP = CLS <= 1 || CLS == 4, bM = CLS <= 1 || CLS == 4, bT = CLS == 1;
-                        if (CLS == 3) { bP = (nPm >> r) & 1u; bM = (kMm >> r) & 1u; bT = (eTm >> r) & 1u; }
+                        bool bP = CLS <= 1 || CLS == 4, bM = CLS <= 1 || CLS == 4;
+                        if (CLS == 3) { bP = (nPm >> r) & 1u; bM = (kMm >> r) & 1u; }
                         int af = 0, bend = 0;
                         if (CLS >= 2) af = __builtin_amdgcn_readlane(dcaf, r0 + r);
                         if (CLS == 1 || CLS == 3 || CLS == 4) bend = __builtin_amdgcn_readlane(dcb, r0 + r);
@@ -1219,7 +1232,6 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                         if (lane == 63) {
                             GST2(gq0 + 2 * r, P_end_v, tagx);
                             GST2(gq0 + 2 * r + 1, Mprev[C - 1], tagx);
-                            if (bT) GST2(gpt0 + r, P_end_v, tagx);
                         }
                     };
                     int r_end = r_e;
@@ -1234,6 +1246,11 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                         for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, PWR_INTERIOR_CLS>{});
                         DG_INC(dg_int, 16)
                         DG_ADD2(dg_cyc_int)
+                    } else if (cls == 1 && r_beg == 0 && r_e == 16) {
+                        // (the band's last strip: its wave has just taken it over and the next strip's wave is waiting for it --
+                        // this is the pipeline's critical path, so whole groups get straight-line code here too)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 1>{});
                     } else {
                         int r = r_beg;
                         for (; r < r_end && (r & 3) && !dead; ++r) group_row(r, std::integral_constant<int, 3>{});
@@ -1248,6 +1265,13 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     }
                     if (!(cls == 0 && r_beg == 0 && r_e == 16)) { DG_INC(dg_gen16, r_end - r_beg) DG_ADD2(dg_cyc_gen16) }
                     x = g0 + r_end;
+#ifdef PWR_DIAG
+                    if (lane == 0 && dg_log < 1900) {
+                        unsigned long long *lg = jb.diag + ((size_t)job * 32 + wave) * 4096 + 256 + 2 * dg_log;
+                        lg[0] = (unsigned long long)x; lg[1] = __builtin_amdgcn_s_memrealtime();
+                    }
+                    dg_log += 1;
+#endif
                     af_done = __builtin_amdgcn_readlane(dcaf, (x - 1) & 63);       // anf of the last row done
                     if ((x & 15) == 0) {                                          // the 16-row group is complete
                         uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;
@@ -1339,7 +1363,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             const unsigned t0 = V3_TICKS();
             for (unsigned spin = 1;; ++spin) {
                 const unsigned long long eQ = LLD(rM[x & (V4_RB - 1)]), eP = LLD(rP[x & (V4_RB - 1)]);
-                const unsigned long long eM = LLD(rM[(x - 1) & (V4_RB - 1)]), eT = LLD(rT[(x - 1) & (V4_RB - 1)]);
+                const unsigned long long eM = LLD(rM[(x - 1) & (V4_RB - 1)]), eT = needT ? GLD(PTOT_PTR(a_prev, Bx_prev, x - 1)) : 0ull;
                 ePx = UNI((unsigned)eP); ePy = UNI((unsigned)eQ); eMy = UNI((unsigned)eM); eTx = UNI((unsigned)eT);
                 const bool ready = (!needP || (UNI(TAGOF(eP)) == tagx && UNI(TAGOF(eQ)) == tagx)) &&
                                    (!needM || UNI(TAGOF(eM)) == tagp) && (!needT || UNI(TAGOF(eT)) == tagp);
@@ -1349,7 +1373,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             }
 #ifdef PWR_DIAG
             if (lane == 0 && dg_general < 36) {
-                unsigned long long *ev = jb.diag + ((size_t)job * 32 + wave) * 128 + 16 + 3 * dg_general;
+                unsigned long long *ev = jb.diag + ((size_t)job * 32 + wave) * 4096 + 16 + 3 * dg_general;
                 ev[0] = (unsigned long long)x; ev[1] = ev_t0; ev[2] = __builtin_amdgcn_s_memrealtime();
             }
 #endif
@@ -1419,7 +1443,6 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         if (lane == 63) {
             GST(gmy + 2 * (size_t)x, P_end, x);
             GST(gmy + 2 * (size_t)x + 1, Mprev[C - 1], x);
-            if (ms == ms_hi) GST(gpt + x, P_end, x);
         }
         ran_prev = 1;
         V4_NEXT_ROW()
@@ -1427,11 +1450,11 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     V4_FLUSH()
 #ifdef PWR_DIAG
     if (lane == 0) {
-        unsigned long long *dgp = jb.diag + ((size_t)job * 32 + wave) * 128;
+        unsigned long long *dgp = jb.diag + ((size_t)job * 32 + wave) * 4096;
         dgp[0] = __builtin_amdgcn_s_memtime() - t_clk0; dgp[1] = dg_wait_fast; dgp[2] = dg_wait_gen; dgp[3] = dg_wait_setup;
         dgp[4] = ((unsigned long long)dg_int << 32) | dg_gen16; dgp[5] = ((unsigned long long)dg_general << 32) | dg_nowork;
         dgp[6] = ((unsigned long long)dg_runs << 32) | dg_switch; dgp[7] = (unsigned long long)L;
-        dgp[8] = dg_cyc_gen16; dgp[9] = dg_ts1; dgp[10] = dg_ts2; dgp[11] = dg_cyc_int;
+        dgp[12] = dg_log; dgp[8] = dg_cyc_gen16; dgp[9] = dg_ts1; dgp[10] = dg_ts2; dgp[11] = dg_cyc_int;
     }
 #endif
     if (lane == 0) LST(wdone, 1);                                                    // releases the fetcher
@@ -1448,6 +1471,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         m->rounds = 0;
         atomicAdd(&st.hdr->cells_computed, m->cells);
     }
+#undef PTOT_PTR
 #undef GLD
 #undef GST
 #undef GST2
@@ -2579,17 +2603,16 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     jb.wpMS = 64 * wpC;
     if ((rc = dmalloc(c, &jb.lastM, (size_t)njobs * jb.NC))) return rc;
     if (c->fill_mode == 4) {
-        const size_t nmb = (size_t)njobs * c->wp_waves * jb.Lmax * 2, npt = (size_t)njobs * jb.Lmax;
+        const size_t nmb = (size_t)njobs * c->wp_waves * jb.Lmax * 2;
         if ((rc = dmalloc(c, &jb.gmb, nmb))) return rc;
-        if ((rc = dmalloc(c, &jb.gpt, npt))) return rc;
         // on the stream the kernels run on (a plain hipMemset is not ordered against it) and waited for
-        if (hipMemsetAsync(jb.gmb, 0, nmb * 8, c->stream) != hipSuccess || hipMemsetAsync(jb.gpt, 0, npt * 8, c->stream) != hipSuccess ||
+        if (hipMemsetAsync(jb.gmb, 0, nmb * 8, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) return PWR_ERR_DEVICE;
         c->fill_epoch = 0;
     }
     if ((rc = dmalloc(c, &jb.gtr, (size_t)njobs * 16))) return rc;
-    if ((rc = dmalloc(c, &jb.diag, (size_t)njobs * 32 * 128))) return rc;
-    if (hipMemsetAsync(jb.diag, 0, (size_t)njobs * 32 * 128 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
+    if ((rc = dmalloc(c, &jb.diag, (size_t)njobs * 32 * 4096))) return rc;
+    if (hipMemsetAsync(jb.diag, 0, (size_t)njobs * 32 * 4096 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     if (hipMemsetAsync(jb.gtr, 0, (size_t)njobs * 16 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     c->trace_epoch = 0;
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
@@ -2602,7 +2625,7 @@ static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
     dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.g64); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
-    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gpt); dfree(c, jb.gtr); dfree(c, jb.diag); dfree(c, c->d_jobrows);
+    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gtr); dfree(c, jb.diag); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -2809,9 +2832,8 @@ static int launch_fill(pwr_ctx *c, int njobs)
         // one work-group (worker + fetcher wave) per wave of the pipeline; grid.x = 8 keeps the work-groups of a DP
         // on one XCD (work-groups go to the XCDs round-robin by linear id)
         if (++c->fill_epoch >= (1u << 15)) {
-            const size_t nmb = (size_t)c->njobs * c->wp_waves * c->jb.Lmax * 2, npt = (size_t)c->njobs * c->jb.Lmax;
+            const size_t nmb = (size_t)c->njobs * c->wp_waves * c->jb.Lmax * 2;
             HIPC(hipMemsetAsync(c->jb.gmb, 0, nmb * 8, c->stream));
-            HIPC(hipMemsetAsync(c->jb.gpt, 0, npt * 8, c->stream));
             c->fill_epoch = 1;
         }
         c->jb.tagbase = c->fill_epoch << 17;
@@ -3200,7 +3222,7 @@ extern "C" int pwr_debug_fill_diag(pwr_ctx *c, unsigned long long *out)
     if (!c || !c->on_device || !out) return PWR_ERR_ARG;
     if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
     HIPC(hipStreamSynchronize(c->stream));
-    HIPC(hipMemcpy(out, c->jb.diag, sizeof(unsigned long long) * 32 * 128, hipMemcpyDeviceToHost));
+    HIPC(hipMemcpy(out, c->jb.diag, sizeof(unsigned long long) * 32 * 4096, hipMemcpyDeviceToHost));
     return PWR_OK;
 }
 
