@@ -1028,8 +1028,22 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     }
 
     DG_DECL
+    // A wave takes its next macro-strip over at the 16-row boundary BEFORE the strip's first row with work: in the rows in
+    // between every cell of the strip lies past the band's end and is masked by the right-hand guard, which leaves exactly the
+    // virtual extension G + Ptot in Mprev (PW:285-295) -- but the strip starts with a whole group of straight-line rows, not
+    // with a stub of rows in the slow one-row loop, right where the pipeline's critical path runs.  The gather's flags do not
+    // know these rows (nor that the strip's first row with work now has a row above it): they are overridden here.
+#define V4_EARLY_MASKS()                                                                         \
+    if (early_hi >= (blk << 6)) {                                                                \
+        const int b0_ = blk << 6;                                                                \
+        const int lo_ = max(early_lo, b0_) - b0_, hi_ = min(early_hi, b0_ + 64) - b0_;           \
+        const unsigned long long me_ = hi_ > lo_ ? ((hi_ - lo_ >= 64 ? ~0ull : ((1ull << (hi_ - lo_)) - 1ull)) << lo_) : 0ull; \
+        const unsigned long long mf_ = early_hi < b0_ + 64 ? 1ull << (early_hi - b0_) : 0ull;    \
+        bOm |= me_ | mf_; bMm |= me_ | mf_; bPm |= me_; bTm |= me_;                              \
+    }
     bool dead = jb.stall_test && job == 0 && wave == 0;                           // (test hook: as if the neighbour never answered)
     int first_pending = 0;                                                       // row x is the wave's first on its macro-strip: the fast path takes it
+    int early_lo = 0, early_hi = -1;                                             // rows [early_lo, early_hi) run ahead of the strip's first row with work, early_hi
     while (x < L && !dead) {
         ran_prev = UNI(ran_prev); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); ms = UNI(ms); cs = UNI(cs); gleft = UNI(gleft);
         x = UNI(x);
@@ -1051,8 +1065,9 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 first_pending = 0;
                 unsigned long long bPm = __builtin_amdgcn_ballot_w64((dcf & 2u) != 0);       // needs the neighbour's running minimum
                 unsigned long long bMm = __builtin_amdgcn_ballot_w64((dcf & 4u) != 0);       // left score = neighbour's M_last(x-1)
-                if (first) { bOm |= 1ull << (x & 63); bMm |= 1ull << (x & 63); }             // (its left score is worked out below)
                 unsigned long long bTm = __builtin_amdgcn_ballot_w64((dcf & 8u) != 0);       // the band ends here: guard against columns past it
+                if (first) { bOm |= 1ull << (x & 63); bMm |= 1ull << (x & 63); }             // (its left score is worked out below)
+                V4_EARLY_MASKS()
                 // per row of the 64-block, one lane each: anf, band end, byte offset of the row's base in the LDS table
                 int dcaf = (int)(dca & 0xffffffu), dcb = min(dcaf + B, W);
                 unsigned dcs = min(dca >> 24, 3u) * (unsigned)(MS * 4);
@@ -1251,6 +1266,10 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                         // this is the pipeline's critical path, so whole groups get straight-line code here too)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 1>{});
+                    } else if (cls == 2 && r_beg == 0 && r_e == 16) {
+                        // (the band's first strip: with every follower close behind its neighbour, its rows set the pace)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 2>{});
                     } else {
                         int r = r_beg;
                         for (; r < r_end && (r & 3) && !dead; ++r) group_row(r, std::integral_constant<int, 3>{});
@@ -1266,9 +1285,10 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     if (!(cls == 0 && r_beg == 0 && r_e == 16)) { DG_INC(dg_gen16, r_end - r_beg) DG_ADD2(dg_cyc_gen16) }
                     x = g0 + r_end;
 #ifdef PWR_DIAG
-                    if (lane == 0 && dg_log < 1900) {
-                        unsigned long long *lg = jb.diag + ((size_t)job * 32 + wave) * 4096 + 256 + 2 * dg_log;
-                        lg[0] = (unsigned long long)x; lg[1] = __builtin_amdgcn_s_memrealtime();
+                    if (lane == 0 && dg_log < 1270) {
+                        unsigned long long *lg = jb.diag + ((size_t)job * 32 + wave) * 4096 + 256 + 3 * dg_log;
+                        lg[0] = (unsigned long long)x | ((unsigned long long)cls << 32) | ((unsigned long long)(r_end - r_beg) << 40); lg[1] = __builtin_amdgcn_s_memrealtime();
+                        lg[2] = dg_wait_fast + dg_wait_gen + dg_wait_setup;
                     }
                     dg_log += 1;
 #endif
@@ -1284,6 +1304,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                         V4_ROTATE_BLOCK()
                         bOm = __builtin_amdgcn_ballot_w64((dcf & 1u) != 0); bPm = __builtin_amdgcn_ballot_w64((dcf & 2u) != 0);
                         bMm = __builtin_amdgcn_ballot_w64((dcf & 4u) != 0); bTm = __builtin_amdgcn_ballot_w64((dcf & 8u) != 0);
+                        V4_EARLY_MASKS()
                         dcaf = (int)(dca & 0xffffffu); dcb = min(dcaf + B, W);
                         dcs = min(dca >> 24, 3u) * (unsigned)(MS * 4);
                         const int *const srow0 = (const int *)(stab + __builtin_amdgcn_readlane((int)dcs, 0));
@@ -1334,10 +1355,20 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             const int y0s = lo + ms * MS;
             const unsigned long long wm = __builtin_amdgcn_ballot_w64(min((int)(dca & 0xffffffu) + B, W) > y0s) >> (x & 63);
             const int xn = min(wm ? x + __builtin_ctzll(wm) : ((x >> 6) + 1) << 6, L);     // (> x: row x itself has no work)
-            const int al = __builtin_amdgcn_readlane((int)dca, (xn - 1) & 63) & 0xffffff;  // row xn - 1 is in this block
-            DG_INC(dg_nowork, xn - x)
-            a_prev = al; Bx_prev = min(B, W - al);
-            x = xn;
+            // (take the strip over at the group boundary before xn, see V4_EARLY_MASKS; the fast path starts it)
+            int xs = xn;
+            if (wm && xn < L - 1) {
+                xs = max(x, xn & ~15);
+                if (xs < 1) xs = xn;
+                early_lo = xs; early_hi = xn;
+                first_pending = xs > 0 ? 1 : 0;
+            }
+            DG_INC(dg_nowork, xs - x)
+            if (xs > x) {
+                const int al = __builtin_amdgcn_readlane((int)dca, (xs - 1) & 63) & 0xffffff;  // row xs - 1 is in this block
+                a_prev = al; Bx_prev = min(B, W - al);
+            }
+            x = xs;
             ran_prev = 0;
             if (lane == 0) LST(wprog, x);
             if (x < L) {
@@ -1471,6 +1502,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         m->rounds = 0;
         atomicAdd(&st.hdr->cells_computed, m->cells);
     }
+#undef V4_EARLY_MASKS
 #undef PTOT_PTR
 #undef GLD
 #undef GST

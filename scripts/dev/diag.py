@@ -30,8 +30,18 @@ for k in ks:
 if os.environ.get("LOG"):
     logs = {}
     for w in range(waves):
-        n = min(buf[w*4096+12], 1900)
-        logs[w] = [(buf[w*4096+256+2*i], buf[w*4096+257+2*i]) for i in range(n)]
+        n = min(buf[w*4096+12], 1270)
+        logs[w] = [(buf[w*4096+256+3*i] & 0xffffffff, buf[w*4096+257+3*i]) for i in range(n)]
+        full = [(buf[w*4096+256+3*i], buf[w*4096+257+3*i], buf[w*4096+258+3*i]) for i in range(n)]
+        if os.environ.get("LOG") == "2" and w in (0, 4):
+            print(f"  ---- wave {w}: per stretch: end row, role, rows, cycles/row busy, cycles/row waiting")
+            pt, pw = None, None
+            for (xc, t, wt) in full:
+                xx, cls_, nr = xc & 0xffffffff, (xc >> 32) & 0xff, xc >> 40
+                if pt is not None and 1000 <= xx <= 1400:
+                    dt = (t - pt) * 10 * 2.39
+                    print(f"       x={xx:5d} role {cls_} rows {nr:2d}: busy {(dt-(wt-pw))/max(nr,1):6.0f}  wait {(wt-pw)/max(nr,1):6.0f}")
+                pt, pw = t, wt
     evs = []
     for w in range(waves):
         ng = min(buf[w*4096+5] >> 32, 36)
