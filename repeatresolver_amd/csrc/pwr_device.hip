@@ -1154,9 +1154,13 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     // where the next strip's wave takes over is exactly where this wave must not dawdle)
                     const unsigned diff = ((nPm ^ (0u - p0)) | (kMm ^ (0u - m0)) | ((p0 & m0) ? 0u : (eTm ^ (0u - t0_)))) & 0xffffu;
                     const int nsame = __builtin_ctz((diff >> r_beg) | 0x10000u);
-                    const int r_e = r_beg + min(nrun, nsame);
+                    // (a WHOLE group whose rows change role on the way is not cut into stretches either: it runs as straight-line
+                    // code with the roles as per-row flags -- the stubs of the one-row loop were where every wave in turn held
+                    // the whole pipeline up)
+                    const bool mixed16 = r_beg == 0 && nrun == 16 && nsame < 16;
+                    const int r_e = mixed16 ? 16 : r_beg + min(nrun, nsame);
                     const unsigned et_here = (eTm >> r_beg) & ((1u << (r_e - r_beg)) - 1u);
-                    const int cls = (p0 & m0) ? (et_here ? 1 : 0) : ((p0 | m0 | t0_) == 0u ? 2 : 3);
+                    const int cls = mixed16 ? 3 : ((p0 & m0) ? (et_here ? 1 : 0) : ((p0 | m0 | t0_) == 0u ? 2 : 3));
                     if (gacc < 0) gacc = x >> 4;
 #ifdef PWR_DIAG
                     if (!dg_ts1 && x >= 1024) dg_ts1 = __builtin_amdgcn_s_memrealtime();
@@ -1266,6 +1270,9 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                         // this is the pipeline's critical path, so whole groups get straight-line code here too)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 1>{});
+                    } else if (cls == 3 && r_beg == 0 && r_e == 16) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 3>{});
                     } else if (cls == 2 && r_beg == 0 && r_e == 16) {
                         // (the band's first strip: with every follower close behind its neighbour, its rows set the pace)
 #pragma unroll
