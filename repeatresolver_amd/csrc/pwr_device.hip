@@ -118,6 +118,7 @@ struct JobBufs {
     unsigned trace_tag;            // 22-bit launch tag of those words
     long long *g64;                // [njobs][colcap] k_fill64: 64-bit prefix sums of S(.,4)
     int force64;                   // test hook: every job takes the 64-bit fill
+    int evcap;                     // commits with more structural events than this renumber by a pass over the width (test hook; <= EVCAP)
     int gate_v2;                   // k_fill_v2 launched behind k_fill_v3: it runs only while Hdr::fallback > 0
     int stall_test;                // test hook: job 0 of this k_fill_v3 launch pretends its neighbour never answers
     unsigned long long *diag;      // [njobs][32][4096] per-wave counters, switch events and a progress log of k_fill_v3 (only written when built with -DPWR_DIAG)
@@ -2098,7 +2099,10 @@ __device__ __forceinline__ int row_symbol(const uint8_t *mk, int y, int lo, int 
     return v == 7 ? 5 : (v ? v - 1 : 4);                  // 7: a blank run between two segments of the row
 }
 
-__device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_i)
+#define EVCAP 1024                  // structural events (columns opened / emptied) of one commit handled without a pass over the width
+struct CommitEv { int key[EVCAP], dl[EVCAP], skey[EVCAP], scum[EVCAP], seg_lo[EVCAP + 1], seg_sh[EVCAP + 1], seg_pre[EVCAP + 2]; };
+
+__device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_i, CommitEv *ev)
 {
     const int tid = threadIdx.x;
     Hdr *h = st.hdr;
@@ -2123,7 +2127,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     const int nfree = h->nfree, nslots = h->nslots;
     const int take = min(nnew, nfree);
     const unsigned newver = (unsigned)h->version + 1u;
-    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[3] = 0; s_i[4] = 0x7fffffff; }   // [0] freed slots, [1] some column lost its last base, [3] any change, [4] first ordinal that changes
+    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[3] = 0; s_i[4] = 0x7fffffff; s_i[5] = 0; }   // [0] freed slots, [1] some column lost its last base, [3] any change, [4] first ordinal that changes, [5] structural events
     for (int y = ny0 + tid; y <= nyL; y += COMMIT_NT) mark2[y - lo] = 0;
     __syncthreads();
     for (int x = tid; x < L; x += COMMIT_NT) {
@@ -2164,6 +2168,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
                 st.colver[slot] = newver;
                 atomicAdd(&st.inscnt[y], 1);
                 atomicMin(&s_i[4], y);
+                { const int e = atomicAdd(&s_i[5], 1); if (e < EVCAP) { ev->key[e] = 2 * y + 1; ev->dl[e] = 1; } }   // a column opens after y
                 aux[x] = slot;
             } else {
                 aux[x] = sloty;
@@ -2189,7 +2194,10 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
             }
             st.colver[slot] = newver;
             s_i[3] = 1;
-            if (w4 == 0) { s_i[1] = 1; atomicMin(&s_i[4], y); }
+            if (w4 == 0) {
+                s_i[1] = 1; atomicMin(&s_i[4], y);
+                const int e = atomicAdd(&s_i[5], 1); if (e < EVCAP) { ev->key[e] = 2 * y; ev->dl[e] = -1; }              // column y loses its last base
+            }
         }
     }
     for (int x = tid; x < L; x += COMMIT_NT) st.pos[off + x] = aux[x];
@@ -2207,11 +2215,73 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         if (tid == 0 && nb) st.nbrk[k] = 0;
     }
     const bool restructure = (nnew > 0) || (s_i[1] != 0);
+    const int nev = s_i[5];
+    const bool inplace = restructure && nev <= jb.evcap;
     int Wnew = W;
-    if (restructure) {
-        // 3. W_Con (PW:706-763) + splice: new ordinal of every surviving / new column.  Columns left of the first one
-        //    that changes keep their ordinal, and the other order buffer already holds them as far as the two agree,
-        //    so the renumbering starts there (rows are realigned left to right: on average half the width is skipped)
+    if (inplace) {
+        // 3a. W_Con (PW:706-763) + splice, the usual case: a handful of columns opened or emptied.  Only the ordinals between
+        //     events whose shifts do not cancel move -- a row that trades a column for its neighbour at either end (what
+        //     every realignment of a converged MSA does) touches a few entries, not the width.  Events are sorted by
+        //     position (key 2y: column y is deleted, 2y+1: a column opens after y); an old ordinal y moves by the sum of the
+        //     events with key < 2y; the moves go through a scratch copy because source and target ranges overlap.
+        for (int e = tid; e < nev; e += COMMIT_NT) {                               // rank sort (nev is small)
+            const int ke = ev->key[e];
+            int r = 0;
+            for (int f = 0; f < nev; ++f) { const int kf = ev->key[f]; r += (kf < ke || (kf == ke && f < e)) ? 1 : 0; }
+            ev->skey[r] = ke; ev->scum[r] = ev->dl[e];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // running sums, and the segments of old ordinals that move: seg k = ordinals (after event k, up to event k+1]
+            int cum = 0, ns = 0, pre = 0;
+            for (int e = 0; e < nev; ++e) {
+                cum += ev->scum[e];
+                ev->scum[e] = cum;
+                const int lo_y = (ev->skey[e] >> 1) + 1;                            // first old ordinal after this event
+                const int hi_y = e + 1 < nev ? ((ev->skey[e + 1] & 1) ? (ev->skey[e + 1] >> 1) + 1 : (ev->skey[e + 1] >> 1)) : W;   // one past the last one before the next (a deleted column is not moved)
+                if (cum != 0 && hi_y > lo_y) { ev->seg_lo[ns] = lo_y; ev->seg_sh[ns] = cum; ev->seg_pre[ns] = pre; pre += hi_y - lo_y; ++ns; }
+            }
+            ev->seg_pre[ns] = pre;
+            s_i[6] = ns; s_i[7] = cum;
+        }
+        __syncthreads();
+        const int ns = s_i[6], total = ev->seg_pre[ns];
+        int *tmp = st.newidx;
+        // freed slots (read before anything moves) and the scratch copy of what moves
+        for (int e = tid; e < nev; e += COMMIT_NT)
+            if (!(ev->skey[e] & 1)) { const int p = atomicAdd(&s_i[0], 1); st.freelist[nfree - take + p] = order[ev->skey[e] >> 1]; }
+        auto seg_of = [&](int i) { int a = 0, b = ns - 1; while (a < b) { const int mid = (a + b + 1) >> 1; if (ev->seg_pre[mid] <= i) a = mid; else b = mid - 1; } return a; };
+        for (int i = tid; i < total; i += COMMIT_NT) { const int sgi = seg_of(i); tmp[i] = order[ev->seg_lo[sgi] + (i - ev->seg_pre[sgi])]; }
+        __threadfence_block();
+        __syncthreads();
+        int *ordw = const_cast<int *>(order);
+        for (int i = tid; i < total; i += COMMIT_NT) {
+            const int sgi = seg_of(i);
+            const int yn = ev->seg_lo[sgi] + (i - ev->seg_pre[sgi]) + ev->seg_sh[sgi];
+            const int slot = tmp[i];
+            ordw[yn] = slot; st.rank[slot] = yn;
+        }
+        // the new columns: after old ordinal y, before any column opened there by a later base of this row (PW:1245-1332)
+        for (int x = tid; x < L; x += COMMIT_NT) {
+            const int c = newcol[x];
+            if (c & 1) {
+                const int y = c >> 1;
+                int t = 0;
+                for (int xx = x - 1; xx >= 0 && newcol[xx] == c; --xx) ++t;        // earlier bases opened there too
+                int a = 0, b = nev;                                                 // events with key < 2y
+                while (a < b) { const int mid = (a + b) >> 1; if (ev->skey[mid] < 2 * y) a = mid + 1; else b = mid; }
+                const int shy = a ? ev->scum[a - 1] : 0;
+                const int kept = (a < nev && ev->skey[a] == 2 * y) ? 0 : 1;         // y itself emptied by this commit?
+                const int pnew = y + shy + kept + t;
+                ordw[pnew] = aux[x]; st.rank[aux[x]] = pnew;
+                st.inscnt[y] = 0;
+            }
+        }
+        Wnew = W + s_i[7];
+    } else if (restructure) {
+        // 3b. the same by a pass over the width (more than EVCAP events): new ordinal of every surviving / new column.  Columns
+        //    left of the first one that changes keep their ordinal, and the other order buffer already holds them as far as
+        //    the two agree, so the renumbering starts there
         const int s0 = max(0, min(s_i[4], h->agree));
         carry = (unsigned)s0;
         for (int base = s0; base < W; base += COMMIT_NT) {
@@ -2253,8 +2323,8 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
             h->W = Wnew;
             h->nslots = nslots + (nnew - take);
             h->nfree = nfree - take + s_i[0];
-            h->cur = cur ^ 1;
-            h->agree = max(0, min(s_i[4], W));
+            if (inplace) h->agree = max(0, min(h->agree, min(s_i[4], W)));         // the other buffer was left alone
+            else { h->cur = cur ^ 1; h->agree = max(0, min(s_i[4], W)); }
         }
         h->version = (int)newver;
         h->cells_reference += m->cells;
@@ -2319,6 +2389,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
 {
     __shared__ unsigned sh[COMMIT_NT / 64];
     __shared__ int s_i[8];
+    __shared__ CommitEv evs;
     Hdr *h = st.hdr;
     if (threadIdx.x == 0) { h->ncommitted = 0; h->stop = 0; }
     __syncthreads();
@@ -2348,7 +2419,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
                 continue;
             }
             if (!validate_job(st, jb, j, sh, s_i)) { if (threadIdx.x == 0) h->stop = 1; stopped = true; continue; }
-            commit_job(st, jb, j, sh, s_i);
+            commit_job(st, jb, j, sh, s_i, &evs);
             live_done += 1;
             if (m->wide && threadIdx.x == 0) h->rows_wide += 1;
         } else if (stopped) continue;
@@ -2465,6 +2536,7 @@ struct pwr_ctx {
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
     int force64 = 0;                      // test hook: every job takes k_fill64
+    int evcap = EVCAP;                    // test hook: event-list renumbering up to this many structural events per commit
     int stall_test = 0;                   // test hook: this many k_fill_v3 launches have their first job stall
     int par_trace = 1;                    // 1: speculative-parallel traceback (k_trace_par), 0: single-wave k_trace_wp
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
@@ -2624,6 +2696,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     const int NC = c->wp_waves * 64 * wpC;
     jb.Lmax = std::max(c->Lmax, 1);
     jb.force64 = c->force64;
+    jb.evcap = c->evcap;
     jb.colcap = c->st.colcap;
     jb.NC = NC;
     jb.dirstride = (size_t)((jb.Lmax + 15) / 16) * NC;
@@ -3154,6 +3227,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
     if (!strcmp(key, "fill")) { if (c->on_device || (value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "stall_test")) { if (value < 0 || value > 1000000) return PWR_ERR_ARG; c->stall_test = (int)value; return PWR_OK; }
+    if (!strcmp(key, "evcap")) { if (value < 0 || value > EVCAP) return PWR_ERR_ARG; c->evcap = (int)value; c->jb.evcap = (int)value; return PWR_OK; }
     if (!strcmp(key, "force64")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->force64 = (int)value; c->jb.force64 = (int)value; return PWR_OK; }
     if (!strcmp(key, "ptrace")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
     if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }

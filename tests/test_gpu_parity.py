@@ -195,6 +195,27 @@ def test_stalled_fill_is_repeated_by_the_one_workgroup_kernel(window, oracle):
     g.close()
 
 
+@pytest.mark.parametrize("evcap", [0, 2])
+def test_commit_renumbering_paths(evcap, oracle):
+    """The commit renumbers the columns from the list of opened / emptied columns when they are few, by a pass over the
+    width otherwise; the hook sets where one gives way to the other (0: always the pass; 2: mixed)."""
+    from repeatresolver_amd.realigner import PWReAligner
+    for name, bw, rounds in (("lowcov_b300", 300, 3), ("toy_a_b50", 50, 2), ("holes_b300", 300, 2)):
+        rows = split_rows(golden_input(name))
+        g = PWReAligner(rows, bandwidth=bw, window=3)
+        g.set_option("evcap", evcap)
+        g.trim_ends()
+        h = oracle.create(rows, bw)
+        oracle.lib.pwo_trim(h)
+        for _ in range(rounds):
+            g.realign_round()
+            oracle.lib.pwo_realign_round(h)
+            assert g.total_score() == oracle.lib.pwo_total_score(h)
+            assert g.export_rows() == oracle.export(h)
+        oracle.lib.pwo_destroy(h)
+        g.close()
+
+
 def test_launch_tag_wraparound(oracle):
     """The mailbox words of k_fill_v3 and the hand-over words of k_trace_par carry a launch counter; when it wraps
     the arrays are cleared and counting restarts.  Start both counters just below their limits."""
