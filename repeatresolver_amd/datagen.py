@@ -132,6 +132,19 @@ def distributed_copies(rng, seq, copynumber, difference):
     return copies
 
 
+def equidistant_copies(rng, seq, copynumber, difference):
+    """DataSimulator.py:72-90 -- every copy gets d/2*len edits of its own (any two copies differ by d)."""
+    snp = int(difference / 2.0 * len(seq))
+    out = []
+    for _c in range(copynumber):
+        b, t = seq.copy(), np.arange(len(seq), dtype=np.int32)
+        for _t in range(snp):
+            position = min(int(rng.random() * len(seq)), len(b) - 1)      # (the reference indexes with the ORIGINAL length)
+            b, t = _apply_edit(rng, b, t, position, rng.random(), int(rng.random() * 3))
+        out.append((b, t))
+    return out
+
+
 def pacbio_error(rng, bases, tpos):
     """Vectorised DataSimulator.py:12-27: per base keep / substitute / delete, then a geometric
     number of random insertions after it."""
@@ -165,8 +178,10 @@ def simulate(cfg: SimConfig) -> SimData:
         copies = tree_copies(rng, seq, cfg.copies, cfg.difference)
     elif cfg.kind == "Distributed":
         copies = distributed_copies(rng, seq, cfg.copies, cfg.difference)
+    elif cfg.kind == "EquiDistant":
+        copies = equidistant_copies(rng, seq, cfg.copies, cfg.difference)
     else:
-        raise ValueError("kind must be Tree or Distributed (EquiDistant is not used by any config)")
+        raise ValueError("kind must be Tree, Distributed or EquiDistant (DataSimulator.py:186)")
     prob = LENGTHS_HISTO / LENGTHS_HISTO.sum()
     data = SimData(template=seq)
     fl = cfg.flank
@@ -192,6 +207,80 @@ def simulate(cfg: SimConfig) -> SimData:
             data.copy_of.append(c)
             data.start_of.append(start)
     return data
+
+
+FLANK_MARK = -2          # tpos of a base that comes from a flank (simulate_dataset)
+
+
+def simulate_dataset(cfg: SimConfig):
+    """The whole of DataSimulator.py:204-262 including what simulate() leaves out: the random flanks, the FULL reads
+    (flank bases included, as `<ds>.fasta` holds them) and the ground truth (`_ReadPlacements`, `_ReadCopynumbers`).
+    Returns (template, full_reads, starts, copy_ids, cut_reads, cut_tpos): cut_reads[i] is the part of read i that the
+    pipeline's ReadCutter keeps -- the stretch sampled from the repeat copy -- or None when the read lies in a flank.
+    (Its own random stream: simulate()'s seeded workloads do not change.)"""
+    rng = np.random.default_rng([cfg.seed, 0x5EED])
+    seq = rng.integers(0, 4, size=cfg.repeat_len, dtype=np.uint8)
+    if cfg.kind == "Tree":
+        copies = tree_copies(rng, seq, cfg.copies, cfg.difference)
+    elif cfg.kind == "Distributed":
+        copies = distributed_copies(rng, seq, cfg.copies, cfg.difference)
+    elif cfg.kind == "EquiDistant":
+        copies = equidistant_copies(rng, seq, cfg.copies, cfg.difference)
+    else:
+        raise ValueError("kind must be Tree, Distributed or EquiDistant (DataSimulator.py:186)")
+    prob = LENGTHS_HISTO / LENGTHS_HISTO.sum()
+    fl = cfg.flank
+    full, starts, cids, cut_b, cut_t = [], [], [], [], []
+    for c, (cb, ct) in enumerate(copies):
+        left = rng.integers(0, 4, size=fl, dtype=np.uint8)                # DataSimulator.py:222-225
+        right = rng.integers(0, 4, size=fl, dtype=np.uint8)
+        gb = np.concatenate((left, cb, right))
+        gt = np.concatenate((np.full(fl, FLANK_MARK, np.int32), ct, np.full(fl, FLANK_MARK, np.int32)))
+        glen = len(gb)
+        covsum, current = 0, 0.0
+        while current < cfg.coverage:                                      # DataSimulator.py:136-152
+            length = int(rng.choice(len(prob), p=prob)) * 1000 + int(rng.random() * 1000)
+            length = min(max(1, int(length * cfg.length_scale)), glen - 1)
+            start = int(rng.random() * (glen - length))
+            covsum += min(glen - fl, start + length) - max(start, fl)
+            current = covsum / float(glen - 2 * fl)
+            rb, rt = pacbio_error(rng, gb[start:start + length], gt[start:start + length])
+            # inserted bases (tpos -1) inside the repeat stretch belong to it: mark origin by the nearest kept base on the left
+            origin = rt.copy()
+            kept = rt != -1
+            if kept.any():
+                idx = np.maximum.accumulate(np.where(kept, np.arange(len(rt)), -1))
+                origin = np.where(idx >= 0, rt[np.maximum(idx, 0)], rt[kept][0])
+            rep = np.nonzero(origin != FLANK_MARK)[0]
+            full.append(rb)
+            starts.append(start)
+            cids.append(c)
+            if len(rep):
+                a, b = int(rep[0]), int(rep[-1]) + 1
+                cut_b.append(rb[a:b])
+                cut_t.append(np.where(rt[a:b] == FLANK_MARK, -1, rt[a:b]).astype(np.int32))
+            else:
+                cut_b.append(None)
+                cut_t.append(None)
+    return seq, full, starts, cids, cut_b, cut_t
+
+
+def write_dataset(prefix: str, cfg: SimConfig) -> dict:
+    """Writes what DataSimulator.py:241-262 writes -- `<prefix>.fasta` (full reads), `<prefix>_ReadPlacements`,
+    `<prefix>_ReadCopynumbers`, `<prefix>_Template.fasta` -- plus `<prefix>Seq.fasta`, the reads cut to their repeat
+    part: the file ReadCutter hands to InitialAligner (ReadCutter.c:953-970; simulated reads hold at most one repeat
+    copy, so cutting at the true boundaries is what it amounts to).  Returns the counts."""
+    seq, full, starts, cids, cut_b, _ = simulate_dataset(cfg)
+    write_fasta(prefix + ".fasta", full)
+    with open(prefix + "_ReadPlacements", "w") as f:
+        f.writelines("%d\n" % s_ for s_ in starts)
+    with open(prefix + "_ReadCopynumbers", "w") as f:
+        f.writelines("%d\n" % c_ for c_ in cids)
+    with open(prefix + "_Template.fasta", "wb") as f:
+        f.write(b">\n" + ASCII[seq].tobytes() + b"\n")                   # one line, DataSimulator.py:259-262
+    cut = [c_ for c_ in cut_b if c_ is not None]
+    write_fasta(prefix + "Seq.fasta", cut)
+    return {"reads": len(full), "cut_reads": len(cut), "template": len(seq)}
 
 
 def build_msa(data: SimData) -> np.ndarray:
