@@ -57,6 +57,7 @@ typedef struct pwr_stats {
     uint64_t reject_reason[4];  /* speculative rejections: interval ends/length, left clamp, right clamp, newer column */
     uint64_t fill_launches_timed; /* launches covered by fill_ms (the first 65536 after a reset) */
     uint64_t stalls;            /* k_fill_v3 jobs given up after a time-out and repeated by k_fill_v2 */
+    uint64_t rows_ahead;        /* commits that went ahead of a stale row of their batch (the two rows commute: disjoint band intervals) */
     uint64_t rows_wide;         /* committed realignments whose scores were not provably below 2^30 and that the 64-bit fill
                                    (the reference's own arithmetic, PW:30, PW:271) computed */
 } pwr_stats;

@@ -46,6 +46,7 @@ struct Hdr {                       // lives in device memory, one per context
     unsigned long long batches, rows_committed, rows_recomputed;   // speculative batches with work; realignments committed / thrown away
     unsigned long long rows_wide;      // committed realignments that were filled by k_fill64
     unsigned long long stalls;         // k_fill_v3 jobs given up because a wave waited too long for its neighbour
+    unsigned long long rows_ahead;     // commits that went ahead of a stale row of the same batch
     int agree, pad0;               // the two order buffers hold the same ordinals for the columns [0, agree)
     // the k loop (PW:1695) is sequenced on the device: a batch realigns the rows rowids[next_row ...], its commit kernel moves
     // next_row on and sizes the next batch, so the host enqueues batches without waiting for their outcome
@@ -56,6 +57,8 @@ struct Hdr {                       // lives in device memory, one per context
     int fallback;                  // > 0: this many batches are filled by k_fill_v2 (one work-group per job, no waiting across work-groups)
     float ema;                     // running mean of rows committed per batch
     int pad2;
+    unsigned long long ahead;      // bit b: row next_row + b was committed ahead of an earlier, stale row it commutes with (its band
+                                   // interval is disjoint from that row's), so the batches to come leave it out
 };
 
 struct Tally {                     // 32 B per column slot
@@ -75,6 +78,7 @@ struct JobMeta {                   // 80 B
     int abort;                     // k_fill_v3: a wave gave up waiting; its siblings leave too
     int active;                    // 0: the job slot is unused in this batch (everything else is left from the last use)
     int wide;                      // 1: the scores may not fit 32 bits: k_fill64 fills this job, the wave pipeline skips it
+    int off, pad;                  // the job's row is rowids[next_row + off]
 };
 
 struct DState {
@@ -235,7 +239,15 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     const int job = blockIdx.x, tid = threadIdx.x;
     JobMeta *m = &jb.meta[job];
     const Hdr *hd = st.hdr;
-    const int kk = hd->next_row + job;
+    // the job's row: the job-th row from next_row on that was not committed ahead of order already
+    int boff = 0;
+    {
+        const unsigned long long ah = hd->ahead;
+        int cnt = -1;
+        for (boff = 0; boff < 64; ++boff) if (!((ah >> boff) & 1ull) && ++cnt == job) break;
+        if (boff == 64) boff = 64 + (job - cnt - 1);
+    }
+    const int kk = hd->next_row + boff;
     if (hd->status != 0 || hd->need_grow || job >= hd->nb || kk >= hd->row_end) {      // no such job in this batch
         if (tid == 0) m->active = 0;
         return;
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
     const int L = st.rowlen[k];
     const int W = st.hdr->W;
     if (L == 0) {
-        if (tid == 0) { m->k = k; m->L = 0; m->ok = 1; m->W = W; m->nnew = 0; m->cells = 0; m->ver = st.hdr->version; m->active = 1; }
+        if (tid == 0) { m->k = k; m->L = 0; m->ok = 1; m->W = W; m->nnew = 0; m->cells = 0; m->ver = st.hdr->version; m->active = 1; m->off = boff; }
         return;
     }
     const long long off = st.rowoff[k];
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         unsigned long long U = 0;
         for (int w = 0; w < GATHER_NT / 64; ++w) U += s_u[w];
         const unsigned long long bound = U + (unsigned long long)mx * (unsigned long long)(2 * B + 4096);
-        m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx; m->abort = 0; m->active = 1;
+        m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx; m->abort = 0; m->active = 1; m->off = boff;
         unsigned long long cs = 0;
         for (int w = 0; w < GATHER_NT / 64; ++w) cs += s_cells[w];
         m->cells = cs; m->ver = st.hdr->version; m->slot_lo = order[lo]; m->slot_hi = order[hi];
@@ -2394,8 +2406,16 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
     if (threadIdx.x == 0) { h->ncommitted = 0; h->stop = 0; }
     __syncthreads();
     if (h->status != 0 || h->need_grow) return;
-    int done = 0, live_done = 0, live_all = 0;
+    // Jobs in row order.  A stale job (its inputs were changed by a commit since the gather) is left for the next batch --
+    // and a later job may still commit AHEAD of it when the two commute: their band intervals [lo, hi] (every column either
+    // DP reads or either commit writes) are disjoint, with a margin for the column a commit may open at its interval's edge.
+    // The DP depends on absolute positions only through the clamps at the MSA's edges, which disjoint intervals rule out
+    // (commutation probe), so realigning j after i gives the state the reference reaches with j before i.
+    __shared__ int sk_lo[128], sk_hi[128];                                        // slots at the ends of the stale jobs' intervals
+    int live_done = 0, live_all = 0, nskip = 0, ahead_n = 0;
+    unsigned long long done_mask = 0;
     bool stopped = false;
+    const int *order_c = cur_order(st);
     for (int j = 0; j < njobs; ++j) {
         JobMeta *m = &jb.meta[j];
         if (!m->active) break;                                                    // the batch ends here
@@ -2418,18 +2438,41 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
                 stopped = true;
                 continue;
             }
-            if (!validate_job(st, jb, j, sh, s_i)) { if (threadIdx.x == 0) h->stop = 1; stopped = true; continue; }
+            bool good = validate_job(st, jb, j, sh, s_i);                         // (on success lo / hi are in today's numbering)
+            if (good && nskip > 0) {
+                order_c = cur_order(st);
+                for (int t = 0; t < nskip && good; ++t) {
+                    const int lo_s = st.rank[sk_lo[t]], hi_s = st.rank[sk_hi[t]];
+                    const bool alive = lo_s >= 0 && lo_s < h->W && hi_s >= 0 && hi_s < h->W && order_c[lo_s] == sk_lo[t] && order_c[hi_s] == sk_hi[t];
+                    if (!alive || !(m->hi + 2 < lo_s || hi_s + 2 < m->lo)) good = false;
+                }
+            }
+            if (!good) {
+                if (threadIdx.x == 0) h->stop = 1;
+                if (nskip >= 128) { stopped = true; continue; }
+                if (threadIdx.x == 0) { sk_lo[nskip] = m->slot_lo; sk_hi[nskip] = m->slot_hi; }
+                nskip += 1;
+                __syncthreads();
+                continue;
+            }
             commit_job(st, jb, j, sh, s_i, &evs);
             live_done += 1;
+            if (nskip > 0) ahead_n += 1;
             if (m->wide && threadIdx.x == 0) h->rows_wide += 1;
-        } else if (stopped) continue;
-        done = j + 1;
+        }
+        // (a row without bases, PW:1488, is done wherever it stands)
+        if (m->off < 64) done_mask |= 1ull << m->off; else stopped = true;
         __syncthreads();
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        const unsigned long long dm = h->ahead | done_mask;
+        const int adv = ~dm ? __builtin_ctzll(~dm) : 64;
+        const int done = __builtin_popcountll(done_mask);
         h->ncommitted = done;
-        h->next_row += done;
+        h->next_row += adv;
+        h->ahead = adv >= 64 ? 0ull : dm >> adv;
+        h->rows_ahead += (unsigned long long)ahead_n;
         if (h->fallback > 0) h->fallback -= 1;
         if (live_all > 0) h->batches += 1;
         h->rows_committed += (unsigned long long)live_done;
@@ -3010,6 +3053,7 @@ static void stats_from_hdr(pwr_ctx *c, const Hdr &h)
     c->stats.rows_recomputed = h.rows_recomputed;
     c->stats.rows_wide = h.rows_wide;
     c->stats.stalls = h.stalls;
+    c->stats.rows_ahead = h.rows_ahead;
     for (int i = 0; i < 4; ++i) c->stats.reject_reason[i] = h.fail_reason[i];
 }
 
@@ -3070,6 +3114,7 @@ static int realign_range(pwr_ctx *c, int k0, int n)
         static_assert(sizeof(init) == offsetof(Hdr, fallback) - offsetof(Hdr, next_row), "slab fields of Hdr");
         HIPC(hipMemcpyAsync(&c->st.hdr->ema, &ema0, sizeof(float), hipMemcpyHostToDevice, c->stream));
         HIPC(hipMemcpyAsync(&c->st.hdr->next_row, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+        HIPC(hipMemsetAsync(&c->st.hdr->ahead, 0, sizeof(unsigned long long), c->stream));
         HIPC(hipStreamSynchronize(c->stream));                                 // (init lives on the stack)
     }
     int rc;
@@ -3277,7 +3322,7 @@ extern "C" int pwr_reset_stats(pwr_ctx *c)
     if (c->on_device) {
         if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
         HIPC(hipStreamSynchronize(c->stream));
-        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 12 * sizeof(unsigned long long)));
+        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 13 * sizeof(unsigned long long)));
     }
     return PWR_OK;
 }

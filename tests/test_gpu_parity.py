@@ -216,6 +216,33 @@ def test_commit_renumbering_paths(evcap, oracle):
         g.close()
 
 
+def test_commit_ahead_of_a_stale_row(oracle):
+    """Many short rows scattered over a wide MSA: batches regularly hold a stale row followed by a valid one whose band
+    interval is disjoint from it; that one commits ahead (the two commute) and the result is still the
+    row-sequential one."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    cfg = dg.SimConfig(kind="Tree", copies=6, coverage=12, difference=0.01, repeat_len=6000, flank=1500,
+                       length_scale=0.03, min_aligned=60, seed=31)
+    rows = [bytes(r) for r in dg.build_msa(dg.simulate(cfg))]
+    lib = oracle.lib
+    for window in (4, 16):
+        g = PWReAligner(rows, bandwidth=100, window=window)
+        g.trim_ends()
+        h = oracle.create(rows, 100)
+        lib.pwo_trim(h)
+        for _ in range(2):
+            g.realign_round()
+            lib.pwo_realign_round(h)
+            assert g.total_score() == lib.pwo_total_score(h)
+            assert g.export_rows() == oracle.export(h)
+        st = g.stats()
+        assert st["rows_ahead"] > 0, st
+        assert st["cells_reference"] == lib.pwo_cells(h)
+        lib.pwo_destroy(h)
+        g.close()
+
+
 def test_launch_tag_wraparound(oracle):
     """The mailbox words of k_fill_v3 and the hand-over words of k_trace_par carry a launch counter; when it wraps
     the arrays are cleared and counting restarts.  Start both counters just below their limits."""
