@@ -104,7 +104,10 @@ struct DState {
     int *newidx;                   // scratch [colcap]
 };
 
+struct GatherPart;
 struct JobBufs {
+    GatherPart *gpart;             // [njobs][GATHER_G] partial results of the gather's shares
+    unsigned gather_tag;           // launch counter of the gather (tags the partial results)
     JobMeta *meta;
     int *way;                      // [njobs][Lmax]   ordinal of every base (PW:31 Way)
     int4 *rec2;                    // [njobs][2*colcap] the same pre-combined for k_fill_v2: {S0-G,S1-G,S2-G,S3-G},{up-G,G,INF-G,0}
@@ -232,82 +235,197 @@ __device__ __forceinline__ const int *cur_order(const DState &st)
 //   w = max(S(y,5), S(y-1,5))  (PW:1507), or PWR_INF where PW:1505 forbids opening a column.
 // ---------------------------------------------------------------------------------------------
 #define GATHER_NT 1024
-__global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, const int *jobrows)
+#define GATHER_G 8                 // work-groups per job: the rows and the interval's columns are cut into that many shares
+struct GatherPart { unsigned long long ucost, cells; unsigned sum4, maxS, lastcov, tag; };   // what a share contributes, tag = launch
+
+// the job's row: the job-th row from next_row on that was not committed ahead of order already; -1: no such job in this batch
+__device__ __forceinline__ int gather_row_of(const Hdr *hd, int job, int *boff_out)
 {
-    __shared__ unsigned sh[GATHER_NT / 64];
-    __shared__ unsigned s_cov[GATHER_NT + 1];
-    const int job = blockIdx.x, tid = threadIdx.x;
+    int boff = 0;
+    const unsigned long long ah = hd->ahead;
+    int cnt = -1;
+    for (boff = 0; boff < 64; ++boff) if (!((ah >> boff) & 1ull) && ++cnt == job) break;
+    if (boff == 64) boff = 64 + (job - cnt - 1);
+    *boff_out = boff;
+    const int kk = hd->next_row + boff;
+    if (hd->status != 0 || hd->need_grow || job >= hd->nb || kk >= hd->row_end) return -1;
+    return kk;
+}
+
+// gather, step a: ordinals of the share's bases (TheWay, PW:647-705), row descriptors and reference cell count for them, marks
+// of the share's columns cleared; share 0 writes the job's header.
+__global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, const int *jobrows)
+{
+    const int job = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     JobMeta *m = &jb.meta[job];
     const Hdr *hd = st.hdr;
-    // the job's row: the job-th row from next_row on that was not committed ahead of order already
-    int boff = 0;
-    {
-        const unsigned long long ah = hd->ahead;
-        int cnt = -1;
-        for (boff = 0; boff < 64; ++boff) if (!((ah >> boff) & 1ull) && ++cnt == job) break;
-        if (boff == 64) boff = 64 + (job - cnt - 1);
-    }
-    const int kk = hd->next_row + boff;
-    if (hd->status != 0 || hd->need_grow || job >= hd->nb || kk >= hd->row_end) {      // no such job in this batch
-        if (tid == 0) m->active = 0;
-        return;
-    }
+    int boff;
+    const int kk = gather_row_of(hd, job, &boff);
+    if (kk < 0) { if (tid == 0 && g == 0) m->active = 0; return; }
     const int k = jobrows[kk];
     const int L = st.rowlen[k];
-    const int W = st.hdr->W;
+    const int W = hd->W;
     if (L == 0) {
-        if (tid == 0) { m->k = k; m->L = 0; m->ok = 1; m->W = W; m->nnew = 0; m->cells = 0; m->ver = st.hdr->version; m->active = 1; m->off = boff; }
+        if (tid == 0 && g == 0) { m->k = k; m->L = 0; m->ok = 1; m->W = W; m->nnew = 0; m->cells = 0; m->ver = hd->version; m->active = 1; m->off = boff; m->wide = 0; m->abort = 0; }
         return;
     }
     const long long off = st.rowoff[k];
     const int *order = cur_order(st);
     int *way = jb.way + (size_t)job * jb.Lmax;
-    for (int x = tid; x < L; x += GATHER_NT) way[x] = st.rank[st.pos[off + x]];
-    __syncthreads();
     const int B = st.B, H = st.H;
-    const int way0 = way[0], wayL = way[L - 1];
+    const int way0 = st.rank[st.pos[off]], wayL = st.rank[st.pos[off + L - 1]];
     const int a0 = max(0, way0 - H), aL = max(0, wayL - H);
     const int lo = max(0, a0 - 1), hi = min(W - 1, aL + B - 1);
     const int n = hi - lo + 1;
+    const int x0 = (int)((long long)L * g / GATHER_G), x1 = (int)((long long)L * (g + 1) / GATHER_G);
+    const int i0 = (int)((long long)n * g / GATHER_G), i1 = (int)((long long)n * (g + 1) / GATHER_G);
     uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
-    int4 *rec2 = jb.rec2 + (size_t)job * jb.colcap * 2;
-    for (int i = tid; i < n; i += GATHER_NT) mark[i] = 0;
+    for (int i = i0 + tid; i < i1; i += GATHER_NT) mark[i] = 0;
+    unsigned long long mycells = 0;
+    uint4 *desc = jb.desc + (size_t)job * jb.Lmax;
+    const int NWg = jb.wpNW, MSg = jb.wpMS;
+    for (int x = x0 + tid; x < x1; x += GATHER_NT) {
+        const int wx = st.rank[st.pos[off + x]];
+        way[x] = wx;
+        const int ax = max(0, wx - H), bx = min(B, W - ax);
+        mycells += (unsigned long long)bx;                                          // cells of DP row x, PW:1496-1499
+        // Row descriptors for the wave-pipeline fills: what every wave would otherwise recompute per DP row (anf < 2^24,
+        // the row's base, and per wave 4 flag bits).  Wave w owns the macro-strip ms = ms_lo + ((w - ms_lo) mod NW) in row x:
+        //   bit0 "ordinary row": the wave has work in rows x-1 and x on the same macro-strip, 0 < x < L-1, and the
+        //        score left of the macro-strip is not the virtual extension G + Ptot(x-1) of PW:285-295
+        //   bit1 needs the left neighbour's running minimum (its macro-strip is not the band's first)
+        //   bit2 the score left of the macro-strip is the neighbour's boundary score of row x-1 (else INF, PW:276)
+        //   bit3 the band ends in this macro-strip
+        const int mlo = (ax - lo) / MSg, mhi = (ax + bx - 1 - lo) / MSg;
+        int ap = 0, bp = 0, plo = 0, phi = -1;
+        if (x > 0) {
+            ap = max(0, st.rank[st.pos[off + x - 1]] - H); bp = min(B, W - ap);
+            plo = (ap - lo) / MSg; phi = (ap + bp - 1 - lo) / MSg;
+        }
+        unsigned long long fl = 0;
+        unsigned fl2 = 0;                                                           // waves 16..23
+        for (int w = 0; w < NWg; ++w) {
+            const int msw = mlo + (((w - mlo) % NWg) + NWg) % NWg;
+            if (msw > mhi) continue;
+            const int msp = plo + (((w - plo) % NWg) + NWg) % NWg;
+            const bool ranp = x > 0 && msp == msw && msp <= phi;
+            const int yq = lo + msw * MSg - 1;
+            const unsigned kind = (x == 0 || yq < ap) ? 0u : (yq < ap + bp ? 1u : 2u);
+            const unsigned bits = ((ranp && x < L - 1 && kind != 2u) ? 1u : 0u) | (msw > mlo ? 2u : 0u) | (kind == 1u ? 4u : 0u) | (msw == mhi ? 8u : 0u);
+            if (w < 16) fl |= (unsigned long long)bits << (4 * w); else fl2 |= bits << (4 * (w - 16));
+        }
+        desc[x] = make_uint4((unsigned)ax | ((unsigned)st.seq[off + x] << 24), (unsigned)fl, (unsigned)(fl >> 32), fl2);
+    }
+    for (int o = 32; o > 0; o >>= 1) mycells += __shfl_xor(mycells, o);
+    __shared__ unsigned long long s_cells[GATHER_NT / 64];
+    if ((tid & 63) == 0) s_cells[tid >> 6] = mycells;
     __syncthreads();
-    for (int x = tid; x < L; x += GATHER_NT) mark[way[x] - lo] = (uint8_t)(st.seq[off + x] + 1);
-    __syncthreads();
-    {
-        // blank runs between the row's segments (rows read with interior blanks, until their first realignment): mark 7
+    if (tid == 0) {
+        unsigned long long cs = 0;
+        for (int w = 0; w < GATHER_NT / 64; ++w) cs += s_cells[w];
+        jb.gpart[(size_t)job * GATHER_G + g].cells = cs;
+        if (g == 0) {
+            m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->abort = 0; m->active = 1; m->off = boff;
+            m->ver = hd->version; m->slot_lo = order[lo]; m->slot_hi = order[hi]; m->ok = 1;
+        }
+    }
+}
+
+// gather, step b: the row's own symbols marked in the interval (bases of the share's rows; blank runs between segments: 7)
+__global__ __launch_bounds__(GATHER_NT) void k_gather_b(DState st, JobBufs jb)
+{
+    const int job = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const JobMeta *m = &jb.meta[job];
+    if (!m->active || m->L <= 0) return;
+    const int L = m->L, k = m->k, lo = m->lo;
+    const long long off = st.rowoff[k];
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
+    const int x0 = (int)((long long)L * g / GATHER_G), x1 = (int)((long long)L * (g + 1) / GATHER_G);
+    for (int x = x0 + tid; x < x1; x += GATHER_NT) mark[way[x] - lo] = (uint8_t)(st.seq[off + x] + 1);
+    if (g == 0) {
+        // blank runs between the row's segments (rows read with interior blanks, until their first realignment)
         const int nb = st.nbrk[k];
         const int *bx = st.brkx + st.brkoff[k];
         for (int t = tid; t < nb; t += GATHER_NT) {
             const int b = bx[t];
             for (int y = way[b] + 1; y < way[b + 1]; ++y) mark[y - lo] = 7;
         }
-        if (nb) __syncthreads();
     }
-    unsigned carry = 0, maxS = 0;
-    unsigned long long ucost = 0;                           // cost of the row where it stands now: an upper bound of the optimum
-    if (tid == 0) s_cov[0] = 0;
-    for (int base = 0; base < n; base += GATHER_NT) {
-        const int i = base + tid;
-        const bool valid = i < n;
-        const int y = lo + i;
-        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
-        if (valid) {
-            const Tally t = st.tally[order[y]];
+}
+
+// gather, step c: Columns_Downdater (PW:1172-1201) into job-private DP inputs for the share's columns.  The prefix sums G run
+// over the whole interval: every share first publishes the sum over its own columns (with the launch's tag), then adds up
+// the shares before it -- they only depend on their own columns, so nobody waits long.  The last share finishes the header.
+__global__ __launch_bounds__(GATHER_NT) void k_gather_c(DState st, JobBufs jb)
+{
+    __shared__ unsigned sh[GATHER_NT / 64];
+    __shared__ unsigned s_cov[GATHER_NT + 1];
+    __shared__ unsigned long long s_u[GATHER_NT / 64];
+    __shared__ unsigned s_carry, s_covl;
+    const int job = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    JobMeta *m = &jb.meta[job];
+    if (!m->active || m->L <= 0) return;
+    const int L = m->L, lo = m->lo, hi = m->hi, W = m->W, B = st.B;
+    const int n = hi - lo + 1;
+    const int *order = cur_order(st);
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const int way0 = way[0], wayL = way[L - 1];
+    const uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
+    int4 *rec2 = jb.rec2 + (size_t)job * jb.colcap * 2;
+    GatherPart *part = jb.gpart + (size_t)job * GATHER_G;
+    const unsigned tag = jb.gather_tag;
+    const int i0 = (int)((long long)n * g / GATHER_G), i1 = (int)((long long)n * (g + 1) / GATHER_G);
+    auto tally_of = [&](int y, uint32_t *w, unsigned long long *uc) {
+        const Tally t = st.tally[order[y]];
 #pragma unroll
-            for (int b = 0; b < 6; ++b) w[b] = t.w[b];
-            if (y >= way0 && y <= wayL) {          // the row's own symbol: a base or '-'
-                const int mk = mark[i];
-                const int own = mk == 7 ? 5 : (mk ? mk - 1 : 4);
+        for (int b = 0; b < 6; ++b) w[b] = t.w[b];
+        if (y >= way0 && y <= wayL) {                                                // the row's own symbol: a base, '-' or (7) blank
+            const int mk = mark[y - lo];
+            const int own = mk == 7 ? 5 : (mk ? mk - 1 : 4);
 #pragma unroll
-                for (int b = 0; b < 6; ++b) w[b] -= (own != 5 && b != own) ? 1u : 0u;
+            for (int b = 0; b < 6; ++b) w[b] -= (own != 5 && b != own) ? 1u : 0u;
+            if (uc) {
 #pragma unroll
-                for (int b = 0; b < 5; ++b) ucost += (b == own) ? w[b] : 0u;
+                for (int b = 0; b < 5; ++b) *uc += (b == own) ? w[b] : 0u;
             }
         }
+    };
+    // pass 1: this share's sum of S(.,4)
+    unsigned mysum = 0;
+    for (int i = i0 + tid; i < i1; i += GATHER_NT) { uint32_t w[6]; tally_of(lo + i, w, nullptr); mysum += w[4]; }
+    for (int o = 32; o > 0; o >>= 1) mysum += __shfl_xor(mysum, o);
+    if ((tid & 63) == 0) sh[tid >> 6] = mysum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < GATHER_NT / 64; ++w) tot += sh[w];
+        __hip_atomic_store(&part[g].sum4, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part[g].tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned carry = 0;
+        for (int q = 0; q < g; ++q) {
+            while (__hip_atomic_load(&part[q].tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(1);
+            carry += __hip_atomic_load(&part[q].sum4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_carry = carry;
+        uint32_t wl[6] = {0, 0, 0, 0, 0, 0};
+        if (i0 > 0) tally_of(lo + i0 - 1, wl, nullptr);                              // coverage of the column left of the share
+        s_covl = wl[5];
+    }
+    __syncthreads();
+    // pass 2: the records
+    unsigned carry = s_carry, maxS = 0;
+    unsigned long long ucost = 0;                                                    // cost of the row where it stands now: an upper bound of the optimum
+    if (tid == 0) s_cov[0] = s_covl;
+    __syncthreads();
+    for (int base = i0; base < i1; base += GATHER_NT) {
+        const int i = base + tid;
+        const bool valid = i < i1;
+        const int y = lo + i;
+        uint32_t w[6] = {0, 0, 0, 0, 0, 0};
+        if (valid) tally_of(y, w, &ucost);
         unsigned tot;
-        const unsigned gin = block_incl_add<GATHER_NT>(w[4], sh, tot);   // barriers inside
+        const unsigned gin = block_incl_add<GATHER_NT>(w[4], sh, tot);               // barriers inside
         s_cov[tid + 1] = w[5];
         __syncthreads();
         const unsigned covl = s_cov[tid];
@@ -315,76 +433,41 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather(DState st, JobBufs jb, con
         if (tid == GATHER_NT - 1) s_cov[0] = w[5];
         if (valid) {
             const unsigned upc = (y == 0 || y == W - 1) ? PWR_INF : max(w[5], covl);
-            const int g = (int)(carry + gin);
-            rec2[2 * i] = make_int4((int)w[0] - g, (int)w[1] - g, (int)w[2] - g, (int)w[3] - g);
-            rec2[2 * i + 1] = make_int4((int)(upc == PWR_INF ? PWR_INF - 1u : upc) - g, g, (int)PWR_INF - g, 0);   // INF-1: pm + up stays below 2^31
+            const int gq = (int)(carry + gin);
+            rec2[2 * i] = make_int4((int)w[0] - gq, (int)w[1] - gq, (int)w[2] - gq, (int)w[3] - gq);
+            rec2[2 * i + 1] = make_int4((int)(upc == PWR_INF ? PWR_INF - 1u : upc) - gq, gq, (int)PWR_INF - gq, 0);   // INF-1: pm + up stays below 2^31
             maxS = max(maxS, max(max(w[0], w[1]), max(max(w[2], w[3]), max(w[4], w[5]))));
         }
         carry += tot;
         __syncthreads();
     }
-    unsigned long long mycells = 0;
-    for (int x = tid; x < L; x += GATHER_NT) {
-        const int ax = max(0, way[x] - H);
-        mycells += (unsigned long long)min(B, W - ax);                      // cells of DP row x, PW:1496-1499
-    }
-    if (jb.wpNW > 0) {
-        // Row descriptors for the wave-pipeline fills: what every wave would otherwise recompute per DP row (anf < 2^24,
-        // the row's base, and per wave 4 flag bits; Bx = min(B, W - anf) is two scalar ops in the kernel).  Wave w owns the
-        // macro-strip ms = ms_lo + ((w - ms_lo) mod NW) in row x; 4 flag bits per wave:
-        //   bit0 "ordinary row": the wave has work in rows x-1 and x on the same macro-strip, 0 < x < L-1, and the
-        //        score left of the macro-strip is not the virtual extension G + Ptot(x-1) of PW:285-295
-        //   bit1 needs the left neighbour's running minimum (its macro-strip is not the band's first)
-        //   bit2 the score left of the macro-strip is the neighbour's boundary score of row x-1 (else INF, PW:276)
-        //   bit3 the band ends in this macro-strip (the wave posts the row's total minimum)
-        uint4 *desc = jb.desc + (size_t)job * jb.Lmax;
-        const int NWg = jb.wpNW, MSg = jb.wpMS;
-        for (int x = tid; x < L; x += GATHER_NT) {
-            const int ax = max(0, way[x] - H), bx = min(B, W - ax);
-            const int mlo = (ax - lo) / MSg, mhi = (ax + bx - 1 - lo) / MSg;
-            int ap = 0, bp = 0, plo = 0, phi = -1;
-            if (x > 0) {
-                ap = max(0, way[x - 1] - H); bp = min(B, W - ap);
-                plo = (ap - lo) / MSg; phi = (ap + bp - 1 - lo) / MSg;
-            }
-            unsigned long long fl = 0;
-            unsigned fl2 = 0;                                                       // waves 16..23
-            for (int w = 0; w < NWg; ++w) {
-                const int msw = mlo + (((w - mlo) % NWg) + NWg) % NWg;
-                if (msw > mhi) continue;
-                const int msp = plo + (((w - plo) % NWg) + NWg) % NWg;
-                const bool ranp = x > 0 && msp == msw && msp <= phi;
-                const int yq = lo + msw * MSg - 1;
-                const unsigned kind = (x == 0 || yq < ap) ? 0u : (yq < ap + bp ? 1u : 2u);
-                const unsigned bits = ((ranp && x < L - 1 && kind != 2u) ? 1u : 0u) | (msw > mlo ? 2u : 0u) | (kind == 1u ? 4u : 0u) | (msw == mhi ? 8u : 0u);
-                if (w < 16) fl |= (unsigned long long)bits << (4 * w); else fl2 |= bits << (4 * (w - 16));
-            }
-            desc[x] = make_uint4((unsigned)ax | ((unsigned)st.seq[off + x] << 24), (unsigned)fl, (unsigned)(fl >> 32), fl2);
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) mycells += __shfl_xor(mycells, o);
-    __shared__ unsigned long long s_cells[GATHER_NT / 64];
-    if ((tid & 63) == 0) s_cells[tid >> 6] = mycells;
-    __syncthreads();
     const unsigned mx = (unsigned)(~block_min_u32<GATHER_NT>(~maxS, sh));
     for (int o = 32; o > 0; o >>= 1) ucost += __shfl_xor(ucost, o);
-    __shared__ unsigned long long s_u[GATHER_NT / 64];
     if ((tid & 63) == 0) s_u[tid >> 6] = ucost;
     __syncthreads();
     if (tid == 0) {
-        // 32-bit range.  The row's present placement is a path inside the band, so the optimum and every
-        // cell on an optimal path are <= U = its cost; larger values may saturate at PWR_INF without
-        // touching any test the traceback makes.  Offsets of at most (2B + slack) * maxS are added on top.
         unsigned long long U = 0;
         for (int w = 0; w < GATHER_NT / 64; ++w) U += s_u[w];
-        const unsigned long long bound = U + (unsigned long long)mx * (unsigned long long)(2 * B + 4096);
-        m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->maxS = mx; m->abort = 0; m->active = 1; m->off = boff;
-        unsigned long long cs = 0;
-        for (int w = 0; w < GATHER_NT / 64; ++w) cs += s_cells[w];
-        m->cells = cs; m->ver = st.hdr->version; m->slot_lo = order[lo]; m->slot_hi = order[hi];
-        // the wave pipeline works with absolute prefix sums G: their total (= bases in the interval) must stay below 2^29
-        m->ok = 1;
-        m->wide = (jb.force64 || !(bound < (unsigned long long)PWR_INF && carry < (1u << 29))) ? 1 : 0;   // -> k_fill64
+        __hip_atomic_store(&part[g].ucost, U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part[g].maxS, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part[g].lastcov, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // "second half done"
+        if (g == GATHER_G - 1) {
+            // 32-bit range.  The row's present placement is a path inside the band, so the optimum and every
+            // cell on an optimal path are <= U = its cost; larger values may saturate at PWR_INF without
+            // touching any test the traceback makes.  Offsets of at most (2B + slack) * maxS are added on top.
+            unsigned long long Ut = 0, cs = 0;
+            unsigned mxt = 0;
+            for (int q = 0; q < GATHER_G; ++q) {
+                while (__hip_atomic_load(&part[q].lastcov, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(1);
+                Ut += __hip_atomic_load(&part[q].ucost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mxt = max(mxt, __hip_atomic_load(&part[q].maxS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                cs += part[q].cells;                                                 // (written by the launch before)
+            }
+            const unsigned long long bound = Ut + (unsigned long long)mxt * (unsigned long long)(2 * B + 4096);
+            m->maxS = mxt; m->cells = cs;
+            // the wave pipeline works with absolute prefix sums G: their total (= bases in the interval) must stay below 2^29
+            m->wide = (jb.force64 || !(bound < (unsigned long long)PWR_INF && carry < (1u << 29))) ? 1 : 0;   // -> k_fill64
+        }
     }
 }
 
@@ -2578,6 +2661,7 @@ struct pwr_ctx {
     int window = 8;
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
+    unsigned gather_tag = 0;              // launch counter of the gather
     int force64 = 0;                      // test hook: every job takes k_fill64
     int evcap = EVCAP;                    // test hook: event-list renumbering up to this many structural events per commit
     int stall_test = 0;                   // test hook: this many k_fill_v3 launches have their first job stall
@@ -2747,6 +2831,8 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     if ((rc = dmalloc(c, &jb.meta, njobs))) return rc;
     if ((rc = dmalloc(c, &jb.way, (size_t)njobs * jb.Lmax))) return rc;
     if ((rc = dmalloc(c, &jb.g64, (size_t)njobs * jb.colcap))) return rc;
+    if ((rc = dmalloc(c, &jb.gpart, (size_t)njobs * GATHER_G))) return rc;
+    if (hipMemsetAsync(jb.gpart, 0, sizeof(GatherPart) * (size_t)njobs * GATHER_G, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     if ((rc = dmalloc(c, &jb.rec2, (size_t)njobs * jb.colcap * 2))) return rc;
     if ((rc = dmalloc(c, &jb.mark, (size_t)njobs * jb.colcap))) return rc;
     if ((rc = dmalloc(c, &jb.mark2, (size_t)njobs * jb.colcap))) return rc;
@@ -2779,7 +2865,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
 static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
-    dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.g64); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
+    dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.g64); dfree(c, jb.gpart); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
     dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gtr); dfree(c, jb.diag); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
@@ -3073,7 +3159,10 @@ static int enqueue_batch(pwr_ctx *c)
 {
     const int n = c->window;
     int rc;
-    hipLaunchKernelGGL(k_gather, dim3(n), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids);
+    c->jb.gather_tag = ++c->gather_tag;
+    hipLaunchKernelGGL(k_gather_a, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids);
+    hipLaunchKernelGGL(k_gather_b, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
+    hipLaunchKernelGGL(k_gather_c, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
     if ((rc = launch_fill(c, n))) return rc;
     hipLaunchKernelGGL(k_fill64, dim3(n), dim3(F64_NT), 0, c->stream, c->st, c->jb);       // jobs the gather flagged wide (none, normally)
     if (c->par_trace) {
