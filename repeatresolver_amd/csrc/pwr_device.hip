@@ -1955,7 +1955,7 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
 //     columns merge within a few rows, so the hand-over chain is short.
 // Results are those of k_trace_wp bit for bit (same per-row step; a step is a function of (row, column)).
 // ---------------------------------------------------------------------------------------------
-#define TRK 16                                          // chunks per job ...
+#define TRK 64                                          // chunks per job ...
 #define TRW 4                                           // ... four to a work-group, so that the chunks of a job spread over four CUs
 #define TR_SPIN_LIMIT (1 << 20)
 // hand-over word of a chunk: [63:42] launch tag, [41:40] 1 = final / 2 = error, [39:24] its 'up' moves, [23:0] exit column + 1
@@ -2851,10 +2851,10 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
             hipStreamSynchronize(c->stream) != hipSuccess) return PWR_ERR_DEVICE;
         c->fill_epoch = 0;
     }
-    if ((rc = dmalloc(c, &jb.gtr, (size_t)njobs * 16))) return rc;
+    if ((rc = dmalloc(c, &jb.gtr, (size_t)njobs * TRK))) return rc;
     if ((rc = dmalloc(c, &jb.diag, (size_t)njobs * 32 * 4096))) return rc;
     if (hipMemsetAsync(jb.diag, 0, (size_t)njobs * 32 * 4096 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
-    if (hipMemsetAsync(jb.gtr, 0, (size_t)njobs * 16 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
+    if (hipMemsetAsync(jb.gtr, 0, (size_t)njobs * TRK * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     c->trace_epoch = 0;
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
     if (hipMemset(jb.meta, 0, sizeof(JobMeta) * njobs) != hipSuccess) return PWR_ERR_DEVICE;
@@ -3166,7 +3166,7 @@ static int enqueue_batch(pwr_ctx *c)
     if ((rc = launch_fill(c, n))) return rc;
     hipLaunchKernelGGL(k_fill64, dim3(n), dim3(F64_NT), 0, c->stream, c->st, c->jb);       // jobs the gather flagged wide (none, normally)
     if (c->par_trace) {
-        if (++c->trace_epoch >= (1u << 22)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * 16 * 8, c->stream)); c->trace_epoch = 1; }
+        if (++c->trace_epoch >= (1u << 22)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * TRK * 8, c->stream)); c->trace_epoch = 1; }
         c->jb.trace_tag = c->trace_epoch;
         hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
     }
