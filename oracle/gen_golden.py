@@ -7,6 +7,7 @@ reference exists (the build container); the GPU box sees just the fixtures.
 
     python oracle/gen_golden.py                 # regenerate the small fixtures (cases.json + *.gz)
     python oracle/gen_golden.py --transposon    # transposon_like.json: digest-only fixture of a run to convergence
+    python oracle/gen_golden.py --ia            # ia_*: fixtures of the reference's InitialAligner
 """
 import hashlib
 import gzip
@@ -143,6 +144,32 @@ def main():
                    "cases": cases}, f, indent=1)
 
 
+def initial_aligner():
+    """Fixtures for the step before PW_ReAligner: template + cut reads from our seeded generator, MSA and
+    SeqClass from the reference's InitialAligner (oracle/_ref/initial_aligner, compiled from the sources in place)."""
+    cases = []
+    for name, kw, cutoff in (
+            ("ia_tree", dict(kind="Tree", copies=4, coverage=6, difference=0.01, repeat_len=1200, flank=400, length_scale=0.07, seed=41), None),
+            ("ia_equi", dict(kind="EquiDistant", copies=5, coverage=5, difference=0.03, repeat_len=800, flank=300, length_scale=0.05, seed=42), None),
+            ("ia_strict", dict(kind="Distributed", copies=3, coverage=6, difference=0.02, repeat_len=1000, flank=600, length_scale=0.08, seed=43), "0.165")):
+        with tempfile.TemporaryDirectory() as td:
+            prefix = os.path.join(td, "x_")
+            dg.write_dataset(prefix, dg.SimConfig(**kw))
+            os.rename(prefix + "_Template.fasta", os.path.join(td, "x_Template.fasta"))
+            args = [IA, "x_Template.fasta", "x_Seq.fasta", "-o", "x_MSA", "-s", "x_SeqClass", "-p", "3"] + (["-e", cutoff] if cutoff else [])
+            p = subprocess.run(args, cwd=td, capture_output=True, check=True)
+            rd = lambda f: open(os.path.join(td, f), "rb").read()
+            write_gz(os.path.join(OUT, name + ".template.gz"), rd("x_Template.fasta"))
+            write_gz(os.path.join(OUT, name + ".reads.gz"), rd("x_Seq.fasta"))
+            write_gz(os.path.join(OUT, name + ".msa.gz"), rd("x_MSA"))
+            cls = rd("x_SeqClass").decode()
+            lines = [l for l in p.stdout.decode("latin1").splitlines() if l.startswith(("template length", "read count", "errorcutoff"))]
+            cases.append({"name": name, "cutoff": float(cutoff) if cutoff else 0.30, "seqclass": cls, "stdout": lines})
+            print(name, lines, "rows", cls.count("r"), "rejected", cls.count("l"), "msa bytes", len(rd("x_MSA")))
+    with open(os.path.join(OUT, "ia_cases.json"), "w") as f:
+        json.dump({"generator": "oracle/gen_golden.py --ia", "reference_build": "gcc -O2 InitialAligner.c -lpthread", "cases": cases}, f, indent=1)
+
+
 def transposon():
     """BASELINE.json configs[4] stand-in at a size whose output (21 MB) is not worth committing: the input is
     regenerated from its seed wherever the test runs, the fixture holds digests and the reference's score lines."""
@@ -160,5 +187,7 @@ def transposon():
 if __name__ == "__main__":
     if "--transposon" in sys.argv[1:]:
         transposon()
+    elif "--ia" in sys.argv[1:]:
+        initial_aligner()
     else:
         main()
