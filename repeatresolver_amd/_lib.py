@@ -22,6 +22,10 @@ EXPORTS = ["pwr_create", "pwr_destroy", "pwr_trim_ends", "pwr_realign_row", "pwr
            "pwr_reset_stats", "pwr_strerror", "pwr_device_count", "pwr_read_msa_file",
            "pwr_write_msa_file", "pwr_run_file"]
 
+# every symbol include/pia.h declares (the InitialAligner)
+PIA_EXPORTS = ["pia_create", "pia_destroy", "pia_align", "pia_get_stats", "pia_read_template", "pia_read_fasta",
+               "pia_build_msa", "pia_run_files"]
+
 _lib = None
 
 
@@ -71,5 +75,21 @@ def load():
     lib.pwr_debug_row_columns.argtypes = [vp, ci, ctypes.POINTER(ci), ci]
     lib.pwr_debug_rounds.restype = ci
     lib.pwr_debug_rounds.argtypes = [vp]
+    ll = ctypes.c_longlong
+    lib.pia_create.restype = ci
+    lib.pia_create.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, ci, ci]
+    lib.pia_destroy.restype = None
+    lib.pia_destroy.argtypes = [vp]
+    lib.pia_align.restype = ci
+    lib.pia_align.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(ll), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    lib.pia_get_stats.restype = ci
+    lib.pia_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]
+    lib.pia_read_template.restype = ci
+    lib.pia_read_template.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ci)]
+    lib.pia_read_fasta.restype = ci
+    lib.pia_read_fasta.argtypes = [ctypes.c_char_p, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+    lib.pia_build_msa.restype = ci
+    lib.pia_build_msa.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ci, ctypes.c_char_p, ctypes.POINTER(ll), ctypes.POINTER(ci),
+                                  ctypes.POINTER(ci), ctypes.c_double, ci]
     _lib = lib
     return lib

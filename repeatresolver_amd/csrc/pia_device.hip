@@ -1,0 +1,317 @@
+// pia_device.hip -- MI355X (gfx950) implementation of the InitialAligner's hot loop behind include/pia.h.
+//
+// Reference: PhilippBongartz/RepeatResolver, InitialAligner.c ("IA:"), IntoAligner (IA:282-453): for every read a full
+// (read length) x (template length) edit-distance matrix with free start and end along the template, one byte of direction
+// per cell, then a traceback.  The reads are independent (the reference strides them over pthreads, IA:457-549).
+//   recurrence (IA:300-328): E(x,y) = min(E(x-1,y-1) + [read x != template y], E(x,y-1) + 1, E(x-1,y) + 1),
+//   E(-1,y) = 0, E(x,-1) = x + 1; ties: diagonal first, then left ONLY IF strictly smaller, then up only if strictly smaller.
+//
+// Unit costs make neighbouring cells differ by -1, 0 or +1, so a row is kept as two bit vectors over the template (Pv: E(x,y) -
+// E(x,y-1) = +1, Mv: = -1) and advanced 32 columns per handful of integer instructions (Myers 1999, in the block form of
+// Hyyro 2001 with a carried-in step delta per word).  What the traceback needs of the reference's direction byte follows from
+// the same vectors:  the diagonal wins (codes 0 / 3, IA:308-312) unless the cell equals its diagonal neighbour although the
+// bases differ (D0 & ~Eq), and then `left` (code 1) wins over `up` (code 2) exactly when E(x,y) = E(x,y-1) + 1 (the new Pv
+// bit), because one of the two must equal the minimum and `up` is only taken when strictly smaller (IA:314-322).
+//
+// One wave owns one read: lane l holds the words [l * WPL, (l + 1) * WPL) of the row vectors in registers and works on read
+// base x = step - l, so the step delta leaving its last word reaches lane l + 1 one step later through a lane shift -- no LDS,
+// no barrier, 64 rows in flight per wave.  Pass 1 stores nothing and yields the distance and the entry column (IA:333-345);
+// the traceback from there cannot leave the diagonal band of half-width `dist` around the entry's diagonal (each step off the
+// diagonal costs one), so pass 2 repeats the rows and stores two bits per cell for that band only -- a tenth of the full
+// matrices at sequencing error rates -- and one thread per read walks the traceback (IA:347-446).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <vector>
+
+#include "pia.h"
+
+#define IA_MAXWPL 35                // 70 000 template bases / (64 lanes x 32 bits)
+
+struct IaRead {
+    long long boff;                 // offset of its bases (and of its alignment) in the call's arrays
+    long long coff;                 // offset (uint2) of its band of direction bits, pass 2
+    int L1;
+    int dist, entry;                // pass 1: Row[entry] and the entry column (IA:333-345); dist = -1: traceback left the band
+    int bw;                         // words per stored row
+};
+
+// first word of the stored band in row x: the columns [c - dist, c + dist] around the entry's diagonal c = entry - (L1 - 1 - x)
+__device__ __forceinline__ int band_word0(const IaRead &rd, int x)
+{
+    const int lo = rd.entry - (rd.L1 - 1 - x) - rd.dist;
+    return (lo > 0 ? lo : 0) >> 5;
+}
+
+template <int WPL, bool STORE>
+__global__ __launch_bounds__(64) void k_ia_bits(const uint32_t *__restrict__ tplanes, int L2, const char *__restrict__ bases,
+                                                IaRead *reads, const int *__restrict__ order, uint2 *__restrict__ codes)
+{
+    IaRead *rdp = &reads[order[blockIdx.x]];
+    const IaRead rd = *rdp;
+    const int L1 = rd.L1, lane = threadIdx.x;
+    if (L1 <= 0) { if (!STORE && lane == 0) { rdp->dist = 0; rdp->entry = L2 - 1; } return; }
+    constexpr int NW = 64 * WPL;
+    // lanes right of the last column that matters never influence the ones left of them
+    const int lastcol = STORE ? rd.entry : L2 - 1;
+    const int lastlane = (lastcol >> 5) / WPL;
+    uint32_t T0[WPL], T1[WPL], Pv[WPL], Mv[WPL];
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) { T0[w] = tplanes[lane * WPL + w]; T1[w] = tplanes[NW + lane * WPL + w]; Pv[w] = 0; Mv[w] = 0; }   // IA:296: row -1 is flat
+    const char *read = bases + rd.boff;
+    int msg = 0;                                  // base code (2 bits) | step delta leaving the lane's last word: +1 (bit 2), -1 (bit 3)
+    int chunk = 0;
+    const int steps = L1 + lastlane;
+    for (int tau = 0; tau < steps; ++tau) {
+        if ((tau & 63) == 0) { const int i = tau + lane; chunk = i < L1 ? (read[i] >> 1) & 3 : 0; }     // a c g t -> 0 1 3 2
+        int m = __shfl_up(msg, 1);
+        const int c0 = __builtin_amdgcn_readlane(chunk, tau & 63);
+        if (lane == 0) m = c0 | 4;                // E(x,-1) - E(x-1,-1) = +1 (IA:301)
+        const int x = tau - lane;
+        if (x >= 0 && x < L1 && lane <= lastlane) {
+            const uint32_t r0 = (m & 1) ? ~0u : 0u, r1 = (m & 2) ? ~0u : 0u;
+            uint32_t hp = (m >> 2) & 1, hn = (m >> 3) & 1;
+            uint2 *row = nullptr;
+            int g0 = 0;
+            if (STORE) { g0 = band_word0(rd, x); row = codes + rd.coff + (size_t)x * rd.bw - g0; }
+#pragma unroll
+            for (int w = 0; w < WPL; ++w) {
+                const uint32_t Eq = ~(T0[w] ^ r0) & ~(T1[w] ^ r1);
+                const uint32_t Xv = Eq | Mv[w], Eqh = Eq | hn;
+                const uint32_t Xh = (((Eqh & Pv[w]) + Pv[w]) ^ Pv[w]) | Eqh;
+                uint32_t Ph = Mv[w] | ~(Xh | Pv[w]), Mh = Pv[w] & Xh;
+                const uint32_t nd = (Xh | Mv[w]) & ~Eq;                 // equals its diagonal neighbour although the bases differ
+                const uint32_t hp2 = Ph >> 31, hn2 = Mh >> 31;
+                Ph = (Ph << 1) | hp; Mh = (Mh << 1) | hn;
+                Pv[w] = Mh | ~(Xv | Ph);
+                Mv[w] = Ph & Xv;
+                hp = hp2; hn = hn2;
+                if (STORE) {
+                    const int g = lane * WPL + w;
+                    if ((unsigned)(g - g0) < (unsigned)rd.bw) row[g] = make_uint2(nd, Pv[w]);
+                }
+            }
+            msg = (m & 3) | (hp << 2) | (hn << 3);
+        }
+    }
+    if (STORE) return;
+    // IA:333-345: minimum of the last row over the columns L2-1 .. 1 (column 0 only if it is the only one), ties -> largest y;
+    // E(L1-1, y) = L1 + sum over j <= y of (Pv - Mv)
+    __shared__ uint32_t sP[64 * WPL], sM[64 * WPL];        // (a walk over register arrays would be unrolled 32 * WPL times)
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < WPL; ++w) { tot += __popc(Pv[w]) - __popc(Mv[w]); sP[lane * WPL + w] = Pv[w]; sM[lane * WPL + w] = Mv[w]; }
+    int incl = tot;
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    int cur = L1 + incl - tot;
+    unsigned long long key = ~0ull;
+#pragma unroll 1
+    for (int w = 0; w < WPL; ++w) {
+        const uint32_t p = sP[lane * WPL + w], q = sM[lane * WPL + w];
+        const int ybase = (lane * WPL + w) * 32;
+#pragma unroll 1
+        for (int b = 0; b < 32; ++b) {
+            cur += (int)((p >> b) & 1u) - (int)((q >> b) & 1u);
+            const int y = ybase + b;
+            if (y < L2 && (y >= 1 || L2 == 1)) {
+                const unsigned long long k2 = ((unsigned long long)(unsigned)cur << 32) | (unsigned)(~(unsigned)y);
+                key = k2 < key ? k2 : key;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(key, o); key = v < key ? v : key; }
+    if (lane == 0) { rdp->dist = (int)(key >> 32); rdp->entry = (int)(~(unsigned)key); }
+}
+
+// IA:347-446: the traceback of one read per thread (independent walks through their own bands)
+__global__ __launch_bounds__(64) void k_ia_trace(int nreads, IaRead *reads, const int *__restrict__ order, const uint2 *__restrict__ codes,
+                                                 int *__restrict__ align)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nreads) return;
+    IaRead *rdp = &reads[order[r]];
+    const IaRead rd = *rdp;
+    const uint2 *cw = codes + rd.coff;
+    int *al = align + rd.boff;
+    int x = rd.L1 - 1, y = rd.entry;                                 // the columns right of the entry are skipped (IA:359-364)
+    while (x > -1 && y > -1) {                                        // IA:366-383
+        const int rel = (y >> 5) - band_word0(rd, x);
+        if ((unsigned)rel >= (unsigned)rd.bw) { rdp->dist = -1; return; }
+        const uint2 v = cw[(size_t)x * rd.bw + rel];
+        const int b = y & 31;
+        if (!((v.x >> b) & 1u)) { al[x] = y; --x; --y; }             // substitution / match: base x sits on template position y
+        else if ((v.y >> b) & 1u) --y;                                // template base skipped
+        else { al[x] = -1; --x; }                                     // read base between two template bases
+    }
+    while (x > -1) { al[x] = -1; --x; }                               // IA:389-394
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct pia_ctx {
+    int device = 0, L2 = 0, WPL = 1;
+    uint32_t *d_planes = nullptr;                 // [2][64 * WPL]: bit y of plane p = bit p of the code of template base y
+    hipStream_t stream = nullptr;
+    unsigned long long cells = 0;
+    double fill_ms = 0.0;
+    size_t mem_budget = (size_t)96 << 30;         // bytes of direction bits per batch of pass 2
+};
+
+#define HIPC(call)                                                                     \
+    do {                                                                               \
+        hipError_t e_ = (call);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            fprintf(stderr, "pia: %s failed: %s\n", #call, hipGetErrorString(e_));    \
+            return PWR_ERR_DEVICE;                                                     \
+        }                                                                              \
+    } while (0)
+
+extern "C" int pia_create(pia_ctx **out, const char *templ, int templ_len, int device)
+{
+    if (!out || !templ || templ_len < 0) return PWR_ERR_ARG;
+    if (templ_len > PIA_MAX_LINE) return PWR_ERR_RANGE;                              // IA:214 Template[70000]
+    pia_ctx *c = new (std::nothrow) pia_ctx();
+    if (!c) return PWR_ERR_NOMEM;
+    c->device = device; c->L2 = templ_len;
+    c->WPL = std::max(1, (templ_len + 2047) / 2048);
+    const int NW = 64 * c->WPL;
+    std::vector<uint32_t> planes(2 * (size_t)NW, 0u);
+    for (int y = 0; y < templ_len; ++y) {
+        const int code = (templ[y] >> 1) & 3;
+        if (code & 1) planes[y >> 5] |= 1u << (y & 31);
+        if (code & 2) planes[NW + (y >> 5)] |= 1u << (y & 31);
+    }
+    if (hipSetDevice(device) != hipSuccess) { delete c; return PWR_ERR_DEVICE; }
+    if (hipMalloc(&c->d_planes, planes.size() * 4) != hipSuccess) { delete c; return PWR_ERR_NOMEM; }
+    if (hipMemcpy(c->d_planes, planes.data(), planes.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipStreamCreate(&c->stream) != hipSuccess) { (void)hipFree(c->d_planes); delete c; return PWR_ERR_DEVICE; }
+    *out = c;
+    return PWR_OK;
+}
+
+extern "C" void pia_destroy(pia_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->d_planes) (void)hipFree(c->d_planes);
+    delete c;
+}
+
+extern "C" int pia_get_stats(pia_ctx *c, unsigned long long *cells, double *fill_ms)
+{
+    if (!c) return PWR_ERR_ARG;
+    if (cells) *cells = c->cells;
+    if (fill_ms) *fill_ms = c->fill_ms;
+    return PWR_OK;
+}
+
+template <int WPL>
+static void launch_bits(pia_ctx *c, bool store, int n, const char *d_bases, IaRead *d_reads, const int *d_order, uint2 *d_codes)
+{
+    if (c->WPL == WPL) {
+        if (store) hipLaunchKernelGGL((k_ia_bits<WPL, true>), dim3(n), dim3(64), 0, c->stream, c->d_planes, c->L2, d_bases, d_reads, d_order, d_codes);
+        else hipLaunchKernelGGL((k_ia_bits<WPL, false>), dim3(n), dim3(64), 0, c->stream, c->d_planes, c->L2, d_bases, d_reads, d_order, d_codes);
+        return;
+    }
+    if constexpr (WPL < IA_MAXWPL) launch_bits<WPL + 1>(c, store, n, d_bases, d_reads, d_order, d_codes);
+}
+
+struct DevBufs {                    // freed on every way out of pia_align
+    char *bases = nullptr; IaRead *reads = nullptr; int *order = nullptr; uint2 *codes = nullptr; int *align = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~DevBufs()
+    {
+        (void)hipFree(bases); (void)hipFree(reads); (void)hipFree(order); (void)hipFree(codes); (void)hipFree(align);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+};
+
+extern "C" int pia_align(pia_ctx *c, int nreads, const char *bases, const long long *off, int *align, int *dist)
+{
+    if (!c || nreads < 0 || !off || (nreads && (!bases || !align || !dist))) return PWR_ERR_ARG;
+    if (nreads == 0) return PWR_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    for (int j = 0; j < nreads; ++j) {
+        const long long l = off[j + 1] - off[j];
+        if (l < 0) return PWR_ERR_ARG;
+        if (l > PIA_MAX_READ) return PWR_ERR_RANGE;                                   // IA:742
+    }
+    const long long b0 = off[0], nb = off[nreads] - off[0];
+    std::vector<IaRead> hr(nreads);
+    std::vector<int> order(nreads);
+    for (int j = 0; j < nreads; ++j) {
+        hr[j].boff = off[j] - b0; hr[j].coff = 0; hr[j].L1 = (int)(off[j + 1] - off[j]); hr[j].dist = 0; hr[j].entry = c->L2 - 1; hr[j].bw = 0;
+        c->cells += (unsigned long long)hr[j].L1 * (unsigned long long)c->L2;
+    }
+    // the longest reads first: the waves that run longest start first
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hr[a].L1 > hr[b].L1; });
+    if (c->L2 == 0) {                                                                 // nothing to align to: every base unaligned
+        for (long long i = 0; i < nb; ++i) align[b0 + i] = -1;
+        for (int j = 0; j < nreads; ++j) dist[j] = hr[j].L1;                          // Row[-1 + 0] is never read by the reference; E(x,-1) = x + 1
+        return PWR_OK;
+    }
+    DevBufs d;
+    HIPC(hipEventCreate(&d.e0)); HIPC(hipEventCreate(&d.e1));
+    if (hipMalloc(&d.bases, std::max<long long>(nb, 1)) != hipSuccess || hipMalloc(&d.reads, sizeof(IaRead) * nreads) != hipSuccess ||
+        hipMalloc(&d.order, sizeof(int) * nreads) != hipSuccess || hipMalloc(&d.align, sizeof(int) * std::max<long long>(nb, 1)) != hipSuccess) return PWR_ERR_NOMEM;
+    if (nb) HIPC(hipMemcpyAsync(d.bases, bases + b0, nb, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemcpyAsync(d.reads, hr.data(), sizeof(IaRead) * nreads, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemcpyAsync(d.order, order.data(), sizeof(int) * nreads, hipMemcpyHostToDevice, c->stream));
+    float ms = 0;
+    // pass 1: distance and entry column of every read
+    HIPC(hipEventRecord(d.e0, c->stream));
+    launch_bits<1>(c, false, nreads, d.bases, d.reads, d.order, nullptr);
+    HIPC(hipGetLastError());
+    HIPC(hipEventRecord(d.e1, c->stream));
+    HIPC(hipMemcpyAsync(hr.data(), d.reads, sizeof(IaRead) * nreads, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (hipEventElapsedTime(&ms, d.e0, d.e1) == hipSuccess) c->fill_ms += ms;
+    // pass 2 in batches whose bands fit the budget
+    size_t maxwords = 0;
+    std::vector<int> bend;                                                            // batch ends in `order`
+    {
+        size_t words = 0;
+        for (int k = 0; k < nreads; ++k) {
+            IaRead &r = hr[order[k]];
+            r.bw = (2 * r.dist) / 32 + 2;
+            const size_t w = (size_t)r.L1 * (size_t)r.bw;
+            if (words && (words + w) * sizeof(uint2) > c->mem_budget) { bend.push_back(k); maxwords = std::max(maxwords, words); words = 0; }
+            r.coff = (long long)words;
+            words += w;
+        }
+        bend.push_back(nreads);
+        maxwords = std::max(maxwords, words);
+    }
+    if (hipMalloc(&d.codes, std::max<size_t>(maxwords, 1) * sizeof(uint2)) != hipSuccess) return PWR_ERR_NOMEM;
+    HIPC(hipMemcpyAsync(d.reads, hr.data(), sizeof(IaRead) * nreads, hipMemcpyHostToDevice, c->stream));
+    int k0 = 0;
+    for (int k1 : bend) {
+        const int n = k1 - k0;
+        HIPC(hipEventRecord(d.e0, c->stream));
+        launch_bits<1>(c, true, n, d.bases, d.reads, d.order + k0, d.codes);
+        HIPC(hipGetLastError());
+        HIPC(hipEventRecord(d.e1, c->stream));
+        hipLaunchKernelGGL(k_ia_trace, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, d.reads, d.order + k0, d.codes, d.align);
+        HIPC(hipGetLastError());
+        HIPC(hipStreamSynchronize(c->stream));
+        if (hipEventElapsedTime(&ms, d.e0, d.e1) == hipSuccess) c->fill_ms += ms;
+        k0 = k1;
+    }
+    if (nb) HIPC(hipMemcpyAsync(align + b0, d.align, sizeof(int) * nb, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipMemcpyAsync(hr.data(), d.reads, sizeof(IaRead) * nreads, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    for (int j = 0; j < nreads; ++j) {
+        if (hr[j].dist < 0) return PWR_ERR_INTERNAL;                                  // a traceback left its band: cannot happen
+        dist[j] = hr[j].dist;
+    }
+    return PWR_OK;
+}

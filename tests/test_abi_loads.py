@@ -21,6 +21,64 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
+    hdr = open(os.path.join(ROOT, "include", "pia.h")).read()
+    declared = set(re.findall(r"\b(pia_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.PIA_EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_initial_aligner_host_side_needs_no_gpu(tmp_path):
+    """FASTA reading (IA:66-262) and Building_MSA (IA:553-663) are host C: fed with the alignments the ORACLE computes,
+    pia_build_msa must write the reference's files (tests/golden/ia_*); the CLI's usage and missing-file exits."""
+    _build()
+    import ctypes
+    import gzip
+    import json
+    import numpy as np
+    from conftest import GOLDEN
+    from repeatresolver_amd import _lib
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "port"], check=True, stdout=subprocess.DEVNULL)
+    lib = _lib.load()
+    ora = ctypes.CDLL(os.path.join(ROOT, "oracle", "libiaoracle.so"))
+    ora.iao_align.restype = ctypes.c_long
+    ora.iao_align.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                              ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+    with open(os.path.join(GOLDEN, "ia_cases.json")) as f:
+        cases = json.load(f)["cases"]
+    for case in cases:
+        t, r = tmp_path / "x_Template.fasta", tmp_path / "x_Seq.fasta"
+        for kind, path in (("template", t), ("reads", r)):
+            with gzip.open(os.path.join(GOLDEN, f"{case['name']}.{kind}.gz"), "rb") as f:
+                path.write_bytes(f.read())
+        tp, L2 = ctypes.c_void_p(), ctypes.c_int()
+        assert lib.pia_read_template(str(t).encode(), ctypes.byref(tp), ctypes.byref(L2)) == 0
+        templ = ctypes.string_at(tp, L2.value)
+        n, bp, op = ctypes.c_int(), ctypes.c_void_p(), ctypes.c_void_p()
+        assert lib.pia_read_fasta(str(r).encode(), ctypes.byref(n), ctypes.byref(bp), ctypes.byref(op)) == 0
+        off = np.ctypeslib.as_array(ctypes.cast(op, ctypes.POINTER(ctypes.c_longlong)), shape=(n.value + 1,)).copy()
+        bases = ctypes.string_at(bp, int(off[-1]))
+        assert set(templ) <= set(b"acgt") and set(bases) <= set(b"acgt") and n.value == case["seqclass"].count("\n")
+        align = np.empty(int(off[-1]), dtype=np.int32)
+        dist = np.empty(n.value, dtype=np.int32)
+        for j in range(n.value):
+            rd = bases[off[j]:off[j + 1]]
+            codes = ctypes.create_string_buffer(len(rd) * L2.value)
+            a = (ctypes.c_int * len(rd))()
+            dist[j] = ora.iao_align(rd, len(rd), templ, L2.value, a, None, codes)
+            align[off[j]:off[j + 1]] = a
+        msa, cls = tmp_path / "msa", tmp_path / "cls"
+        assert lib.pia_build_msa(str(msa).encode(), str(cls).encode(), n.value, bases,
+                                 off.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)), align.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                 dist.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), case["cutoff"], L2.value) == 0
+        assert cls.read_text() == case["seqclass"]
+        with gzip.open(os.path.join(GOLDEN, f"{case['name']}.msa.gz"), "rb") as f:
+            assert msa.read_bytes() == f.read()
+    cli = os.path.join(ROOT, "repeatresolver_amd", "csrc", "InitialAligner")
+    p = subprocess.run([cli], capture_output=True)
+    assert p.returncode == 0 and p.stdout.startswith(b"Usage: ./InitialAligner_parallel template.fasta Seq.fasta\n")   # IA:272
+    p = subprocess.run([cli, str(tmp_path / "nope_Template.fasta"), str(tmp_path / "x_Seq.fasta")], capture_output=True)
+    assert p.returncode == 1                                                                                              # IA:226
 
 
 def test_host_text_path_needs_no_gpu(tmp_path):
