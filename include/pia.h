@@ -35,6 +35,12 @@ void pia_destroy(pia_ctx *ctx);
 int pia_align(pia_ctx *ctx, int nreads, const char *bases, const long long *off, int *align, int *dist);
 /* DP cells filled so far (read length x template length per read) and the summed duration of the fill kernel in ms. */
 int pia_get_stats(pia_ctx *ctx, unsigned long long *cells, double *fill_ms);
+/* "mem_budget": bytes of device memory for the stored direction bits of one batch of reads (0 = the default, 22 GB; up to
+ * four such buffers are in flight); a read whose band alone is larger still gets a batch of its own. */
+int pia_set_option(pia_ctx *ctx, const char *key, long long value);
+/* Where the last pia_align spent its time, ms: [0] all of it, [1] set-up and upload, [2] pass 1, [3] pass 2 with the
+ * tracebacks, [4] the number of batches pass 2 took (not a time), [5] download. */
+int pia_get_timing(pia_ctx *ctx, double *ms6);
 
 /* ---- host side, plain C (pia_host.c) ---- */
 /* ReadingTemplate (IA:214-262): every line that does not start with '>' contributes its aAcCgGtT, lower-cased. */

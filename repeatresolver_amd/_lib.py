@@ -23,7 +23,7 @@ EXPORTS = ["pwr_create", "pwr_destroy", "pwr_trim_ends", "pwr_realign_row", "pwr
            "pwr_write_msa_file", "pwr_run_file"]
 
 # every symbol include/pia.h declares (the InitialAligner)
-PIA_EXPORTS = ["pia_create", "pia_destroy", "pia_align", "pia_get_stats", "pia_read_template", "pia_read_fasta",
+PIA_EXPORTS = ["pia_create", "pia_destroy", "pia_align", "pia_get_stats", "pia_set_option", "pia_get_timing", "pia_read_template", "pia_read_fasta",
                "pia_build_msa", "pia_run_files"]
 
 _lib = None
@@ -84,6 +84,10 @@ def load():
     lib.pia_align.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(ll), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.pia_get_stats.restype = ci
     lib.pia_get_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_double)]
+    lib.pia_set_option.restype = ci
+    lib.pia_set_option.argtypes = [vp, ctypes.c_char_p, ll]
+    lib.pia_get_timing.restype = ci
+    lib.pia_get_timing.argtypes = [vp, ctypes.POINTER(ctypes.c_double)]
     lib.pia_read_template.restype = ci
     lib.pia_read_template.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ci)]
     lib.pia_read_fasta.restype = ci

@@ -18,13 +18,14 @@
 // no barrier, 64 rows in flight per wave.  Pass 1 stores nothing and yields the distance and the entry column (IA:333-345);
 // the traceback from there cannot leave the diagonal band of half-width `dist` around the entry's diagonal (each step off the
 // diagonal costs one), so pass 2 repeats the rows and stores two bits per cell for that band only -- a tenth of the full
-// matrices at sequencing error rates -- and one thread per read walks the traceback (IA:347-446).
+// matrices at sequencing error rates -- and the same wave then walks the traceback (IA:347-446) through what it has stored.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <numeric>
 #include <vector>
@@ -32,31 +33,82 @@
 #include "pia.h"
 
 #define IA_MAXWPL 35                // 70 000 template bases / (64 lanes x 32 bits)
+#define IA_NBUF 4                   // batches of pass 2 in flight, each with its buffer and stream
 
 struct IaRead {
     long long boff;                 // offset of its bases (and of its alignment) in the call's arrays
     long long coff;                 // offset (uint2) of its band of direction bits, pass 2
     int L1;
     int dist, entry;                // pass 1: Row[entry] and the entry column (IA:333-345); dist = -1: traceback left the band
-    int bw;                         // words per stored row
+    int nl;                         // lanes stored per row (pass 2)
 };
 
-// first word of the stored band in row x: the columns [c - dist, c + dist] around the entry's diagonal c = entry - (L1 - 1 - x)
-__device__ __forceinline__ int band_word0(const IaRead &rd, int x)
+// The stored band of row x are the columns [c - dist, c + dist] around the entry's diagonal c = entry - (L1 - 1 - x), widened
+// to whole lanes (32 * WPL columns each): first stored lane of row x
+__device__ __forceinline__ int band_lane0(const IaRead &rd, int x, int colshift_mul)
 {
     const int lo = rd.entry - (rd.L1 - 1 - x) - rd.dist;
-    return (lo > 0 ? lo : 0) >> 5;
+    return (int)(((unsigned)(lo > 0 ? lo : 0) >> 5) / (unsigned)colshift_mul);
+}
+
+// IA:347-446, the traceback, walked by the wave that has just stored the read's band.  The walk is one chain of dependent
+// steps, so it is kept in scalar registers: each round, lane i fetches the three words of row x - i around the diagonal from
+// the current cell (64 rows per memory latency), the wave then steps through them with v_readlane, and lane i keeps the
+// placement of its row for one coalesced store.  A step that needs a word outside the fetched three starts the next round.
+template <int WPL>
+__device__ __forceinline__ void wave_trace(const IaRead &rd, IaRead *rdp, const uint2 *__restrict__ cw, int *__restrict__ al, int lane)
+{
+    constexpr int WPS = (WPL + 1) & ~1;
+    int x = rd.L1 - 1, y = rd.entry;                                  // the columns right of the entry are skipped (IA:359-364)
+    bool lost = false;
+    while (x >= 0 && y >= 0) {                                        // IA:366-383
+        const int xtop = x, ytop = y;
+        const int xr = xtop - lane, gb = (ytop - lane) >> 5;          // lane i: row xtop - i, the word of column ytop - i
+        uint2 w0 = make_uint2(0u, 0u), w1 = w0, w2 = w0;
+        if (xr >= 0 && gb >= -1) {
+            const int l0 = band_lane0(rd, xr, WPL);
+            const uint2 *rowp = cw + (size_t)xr * rd.nl * WPS;
+            auto ld = [&](int g, uint2 &v) {
+                const int ln = g / WPL, rel = ln - l0;
+                if (g >= 0 && g < 64 * WPL && (unsigned)rel < (unsigned)rd.nl) v = rowp[rel * WPS + (g - ln * WPL)];
+            };
+            ld(gb - 1, w0); ld(gb, w1); ld(gb + 1, w2);
+        }
+        int myal = -1;
+        for (;;) {
+            const int k = xtop - x;
+            if (k >= 64 || x < 0 || y < 0) break;
+            const int g = y >> 5, b = y & 31;
+            const int j = g - ((ytop - k) >> 5) + 1;
+            if ((unsigned)j > 2u) break;                              // (never at k = 0: every round moves on)
+            if ((unsigned)(g / WPL - band_lane0(rd, x, WPL)) >= (unsigned)rd.nl) { lost = true; break; }
+            uint32_t nd, lf;
+            if (j == 0) { nd = __builtin_amdgcn_readlane(w0.x, k); lf = __builtin_amdgcn_readlane(w0.y, k); }
+            else if (j == 1) { nd = __builtin_amdgcn_readlane(w1.x, k); lf = __builtin_amdgcn_readlane(w1.y, k); }
+            else { nd = __builtin_amdgcn_readlane(w2.x, k); lf = __builtin_amdgcn_readlane(w2.y, k); }
+            if (!((nd >> b) & 1u)) {                                  // substitution / match: base x sits on template position y
+                if (lane == k) myal = y;
+                x = __builtin_amdgcn_readfirstlane(x - 1); y = __builtin_amdgcn_readfirstlane(y - 1);
+            } else if ((lf >> b) & 1u) y = __builtin_amdgcn_readfirstlane(y - 1);      // template base skipped
+            else x = __builtin_amdgcn_readfirstlane(x - 1);           // read base between two template bases: stays -1
+        }
+        if (lost) break;
+        if (lane < xtop - x) al[xtop - lane] = myal;                  // the rows this round has finished
+    }
+    if (lost) { if (lane == 0) rdp->dist = -1; return; }              // left the stored band: cannot happen
+    for (int i = x - lane; i >= 0; i -= 64) al[i] = -1;               // IA:389-394
 }
 
 template <int WPL, bool STORE>
 __global__ __launch_bounds__(64) void k_ia_bits(const uint32_t *__restrict__ tplanes, int L2, const char *__restrict__ bases,
-                                                IaRead *reads, const int *__restrict__ order, uint2 *__restrict__ codes)
+                                                IaRead *reads, const int *__restrict__ order, uint2 *__restrict__ codes, int *__restrict__ align)
 {
     IaRead *rdp = &reads[order[blockIdx.x]];
     const IaRead rd = *rdp;
     const int L1 = rd.L1, lane = threadIdx.x;
     if (L1 <= 0) { if (!STORE && lane == 0) { rdp->dist = 0; rdp->entry = L2 - 1; } return; }
     constexpr int NW = 64 * WPL;
+    constexpr int WPS = (WPL + 1) & ~1;           // stored words per lane and row (even: 16-byte stores)
     // lanes right of the last column that matters never influence the ones left of them
     const int lastcol = STORE ? rd.entry : L2 - 1;
     const int lastlane = (lastcol >> 5) / WPL;
@@ -76,9 +128,7 @@ __global__ __launch_bounds__(64) void k_ia_bits(const uint32_t *__restrict__ tpl
         if (x >= 0 && x < L1 && lane <= lastlane) {
             const uint32_t r0 = (m & 1) ? ~0u : 0u, r1 = (m & 2) ? ~0u : 0u;
             uint32_t hp = (m >> 2) & 1, hn = (m >> 3) & 1;
-            uint2 *row = nullptr;
-            int g0 = 0;
-            if (STORE) { g0 = band_word0(rd, x); row = codes + rd.coff + (size_t)x * rd.bw - g0; }
+            uint32_t ND[STORE ? WPL : 1];
 #pragma unroll
             for (int w = 0; w < WPL; ++w) {
                 const uint32_t Eq = ~(T0[w] ^ r0) & ~(T1[w] ^ r1);
@@ -91,15 +141,29 @@ __global__ __launch_bounds__(64) void k_ia_bits(const uint32_t *__restrict__ tpl
                 Pv[w] = Mh | ~(Xv | Ph);
                 Mv[w] = Ph & Xv;
                 hp = hp2; hn = hn2;
-                if (STORE) {
-                    const int g = lane * WPL + w;
-                    if ((unsigned)(g - g0) < (unsigned)rd.bw) row[g] = make_uint2(nd, Pv[w]);
-                }
+                if (STORE) ND[w] = nd;
             }
             msg = (m & 3) | (hp << 2) | (hn << 3);
+            if (STORE) {
+                // few lanes of a wave are inside the band at any step: they store all their words, no test per word.
+                // (Measured on the benchmark reads: pass 2 takes 54 ms without these stores, 84 ms with them -- each lane's
+                // 128-byte line leaves as eight 16-byte requests; staging a step's lines in LDS for whole-line stores is
+                // the next step.  The traceback behind it adds 4 ms.)
+                const int rel = lane - band_lane0(rd, x, WPL);
+                if ((unsigned)rel < (unsigned)rd.nl) {
+                    uint2 *dst = codes + rd.coff + ((size_t)x * rd.nl + rel) * WPS;
+#pragma unroll
+                    for (int w = 0; w + 1 < WPL; w += 2) *reinterpret_cast<uint4 *>(dst + w) = make_uint4(ND[w], Pv[w], ND[w + 1], Pv[w + 1]);
+                    if (WPL & 1) dst[WPL - 1] = make_uint2(ND[WPL - 1], Pv[WPL - 1]);
+                }
+            }
         }
     }
-    if (STORE) return;
+    if (STORE) {
+        __threadfence();                          // the band is read back by other lanes of this wave
+        wave_trace<WPL>(rd, rdp, codes + rd.coff, align + rd.boff, lane);
+        return;
+    }
     // IA:333-345: minimum of the last row over the columns L2-1 .. 1 (column 0 only if it is the only one), ties -> largest y;
     // E(L1-1, y) = L1 + sum over j <= y of (Pv - Mv)
     __shared__ uint32_t sP[64 * WPL], sM[64 * WPL];        // (a walk over register arrays would be unrolled 32 * WPL times)
@@ -128,39 +192,21 @@ __global__ __launch_bounds__(64) void k_ia_bits(const uint32_t *__restrict__ tpl
     if (lane == 0) { rdp->dist = (int)(key >> 32); rdp->entry = (int)(~(unsigned)key); }
 }
 
-// IA:347-446: the traceback of one read per thread (independent walks through their own bands)
-__global__ __launch_bounds__(64) void k_ia_trace(int nreads, IaRead *reads, const int *__restrict__ order, const uint2 *__restrict__ codes,
-                                                 int *__restrict__ align)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nreads) return;
-    IaRead *rdp = &reads[order[r]];
-    const IaRead rd = *rdp;
-    const uint2 *cw = codes + rd.coff;
-    int *al = align + rd.boff;
-    int x = rd.L1 - 1, y = rd.entry;                                 // the columns right of the entry are skipped (IA:359-364)
-    while (x > -1 && y > -1) {                                        // IA:366-383
-        const int rel = (y >> 5) - band_word0(rd, x);
-        if ((unsigned)rel >= (unsigned)rd.bw) { rdp->dist = -1; return; }
-        const uint2 v = cw[(size_t)x * rd.bw + rel];
-        const int b = y & 31;
-        if (!((v.x >> b) & 1u)) { al[x] = y; --x; --y; }             // substitution / match: base x sits on template position y
-        else if ((v.y >> b) & 1u) --y;                                // template base skipped
-        else { al[x] = -1; --x; }                                     // read base between two template bases
-    }
-    while (x > -1) { al[x] = -1; --x; }                               // IA:389-394
-}
-
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 struct pia_ctx {
     int device = 0, L2 = 0, WPL = 1;
     uint32_t *d_planes = nullptr;                 // [2][64 * WPL]: bit y of plane p = bit p of the code of template base y
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                 // = streams[0]
+    hipStream_t streams[IA_NBUF] = {};
+    uint2 *codes[IA_NBUF] = {};                   // direction bits of the batches of pass 2 in flight, kept between calls
+    size_t codes_cap[IA_NBUF] = {};               // in uint2
     unsigned long long cells = 0;
     double fill_ms = 0.0;
-    size_t mem_budget = (size_t)96 << 30;         // bytes of direction bits per batch of pass 2
+    double t_ms[6] = {0, 0, 0, 0, 0, 0};          // last pia_align: total, set-up + upload, pass 1, pass 2 with the tracebacks, its batches, download
+    size_t mem_budget = 0;                        // bytes of direction bits per batch of pass 2; 0: 22 GB (measured: the first ~96 GB a process
+                                                  // allocates come at once, every further GB takes 30 ms)
 };
 
 #define HIPC(call)                                                                     \
@@ -190,7 +236,13 @@ extern "C" int pia_create(pia_ctx **out, const char *templ, int templ_len, int d
     if (hipSetDevice(device) != hipSuccess) { delete c; return PWR_ERR_DEVICE; }
     if (hipMalloc(&c->d_planes, planes.size() * 4) != hipSuccess) { delete c; return PWR_ERR_NOMEM; }
     if (hipMemcpy(c->d_planes, planes.data(), planes.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipStreamCreate(&c->stream) != hipSuccess) { (void)hipFree(c->d_planes); delete c; return PWR_ERR_DEVICE; }
+        hipStreamCreate(&c->streams[0]) != hipSuccess || hipStreamCreate(&c->streams[1]) != hipSuccess ||
+        hipStreamCreate(&c->streams[2]) != hipSuccess || hipStreamCreate(&c->streams[3]) != hipSuccess) {
+        for (hipStream_t st : c->streams) if (st) (void)hipStreamDestroy(st);
+        (void)hipFree(c->d_planes); delete c; return PWR_ERR_DEVICE;
+    }
+    static_assert(IA_NBUF == 4, "one hipStreamCreate per buffer above");
+    c->stream = c->streams[0];
     *out = c;
     return PWR_OK;
 }
@@ -199,8 +251,9 @@ extern "C" void pia_destroy(pia_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (hipStream_t st : c->streams) if (st) (void)hipStreamDestroy(st);
     if (c->d_planes) (void)hipFree(c->d_planes);
+    for (uint2 *p : c->codes) (void)hipFree(p);
     delete c;
 }
 
@@ -212,23 +265,46 @@ extern "C" int pia_get_stats(pia_ctx *c, unsigned long long *cells, double *fill
     return PWR_OK;
 }
 
+extern "C" int pia_set_option(pia_ctx *c, const char *key, long long value)
+{
+    if (!c || !key) return PWR_ERR_ARG;
+    if (!strcmp(key, "mem_budget")) { if (value < 0) return PWR_ERR_ARG; c->mem_budget = (size_t)value; return PWR_OK; }
+    return PWR_ERR_ARG;
+}
+
+extern "C" int pia_get_timing(pia_ctx *c, double *ms6)
+{
+    if (!c || !ms6) return PWR_ERR_ARG;
+    for (int i = 0; i < 6; ++i) ms6[i] = c->t_ms[i];
+    return PWR_OK;
+}
+
+static double now_ms()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
 template <int WPL>
-static void launch_bits(pia_ctx *c, bool store, int n, const char *d_bases, IaRead *d_reads, const int *d_order, uint2 *d_codes)
+static void launch_bits(pia_ctx *c, bool store, int n, const char *d_bases, IaRead *d_reads, const int *d_order, uint2 *d_codes, int *d_align, hipStream_t st)
 {
     if (c->WPL == WPL) {
-        if (store) hipLaunchKernelGGL((k_ia_bits<WPL, true>), dim3(n), dim3(64), 0, c->stream, c->d_planes, c->L2, d_bases, d_reads, d_order, d_codes);
-        else hipLaunchKernelGGL((k_ia_bits<WPL, false>), dim3(n), dim3(64), 0, c->stream, c->d_planes, c->L2, d_bases, d_reads, d_order, d_codes);
+        if (store) hipLaunchKernelGGL((k_ia_bits<WPL, true>), dim3(n), dim3(64), 0, st, c->d_planes, c->L2, d_bases, d_reads, d_order, d_codes, d_align);
+        else hipLaunchKernelGGL((k_ia_bits<WPL, false>), dim3(n), dim3(64), 0, st, c->d_planes, c->L2, d_bases, d_reads, d_order, d_codes, d_align);
         return;
     }
-    if constexpr (WPL < IA_MAXWPL) launch_bits<WPL + 1>(c, store, n, d_bases, d_reads, d_order, d_codes);
+    if constexpr (WPL < IA_MAXWPL) launch_bits<WPL + 1>(c, store, n, d_bases, d_reads, d_order, d_codes, d_align, st);
 }
 
 struct DevBufs {                    // freed on every way out of pia_align
-    char *bases = nullptr; IaRead *reads = nullptr; int *order = nullptr; uint2 *codes = nullptr; int *align = nullptr;
+    char *bases = nullptr; IaRead *reads = nullptr; int *order = nullptr; int *align = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<hipEvent_t> ev;
     ~DevBufs()
     {
-        (void)hipFree(bases); (void)hipFree(reads); (void)hipFree(order); (void)hipFree(codes); (void)hipFree(align);
+        (void)hipFree(bases); (void)hipFree(reads); (void)hipFree(order); (void)hipFree(align);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     }
@@ -244,11 +320,13 @@ extern "C" int pia_align(pia_ctx *c, int nreads, const char *bases, const long l
         if (l < 0) return PWR_ERR_ARG;
         if (l > PIA_MAX_READ) return PWR_ERR_RANGE;                                   // IA:742
     }
+    const double t_start = now_ms();
+    for (double &t : c->t_ms) t = 0;
     const long long b0 = off[0], nb = off[nreads] - off[0];
     std::vector<IaRead> hr(nreads);
     std::vector<int> order(nreads);
     for (int j = 0; j < nreads; ++j) {
-        hr[j].boff = off[j] - b0; hr[j].coff = 0; hr[j].L1 = (int)(off[j + 1] - off[j]); hr[j].dist = 0; hr[j].entry = c->L2 - 1; hr[j].bw = 0;
+        hr[j].boff = off[j] - b0; hr[j].coff = 0; hr[j].L1 = (int)(off[j + 1] - off[j]); hr[j].dist = 0; hr[j].entry = c->L2 - 1; hr[j].nl = 0;
         c->cells += (unsigned long long)hr[j].L1 * (unsigned long long)c->L2;
     }
     // the longest reads first: the waves that run longest start first
@@ -267,45 +345,63 @@ extern "C" int pia_align(pia_ctx *c, int nreads, const char *bases, const long l
     HIPC(hipMemcpyAsync(d.reads, hr.data(), sizeof(IaRead) * nreads, hipMemcpyHostToDevice, c->stream));
     HIPC(hipMemcpyAsync(d.order, order.data(), sizeof(int) * nreads, hipMemcpyHostToDevice, c->stream));
     float ms = 0;
+    HIPC(hipStreamSynchronize(c->stream));
+    c->t_ms[1] = now_ms() - t_start;
     // pass 1: distance and entry column of every read
     HIPC(hipEventRecord(d.e0, c->stream));
-    launch_bits<1>(c, false, nreads, d.bases, d.reads, d.order, nullptr);
+    launch_bits<1>(c, false, nreads, d.bases, d.reads, d.order, nullptr, nullptr, c->stream);
     HIPC(hipGetLastError());
     HIPC(hipEventRecord(d.e1, c->stream));
     HIPC(hipMemcpyAsync(hr.data(), d.reads, sizeof(IaRead) * nreads, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
-    if (hipEventElapsedTime(&ms, d.e0, d.e1) == hipSuccess) c->fill_ms += ms;
-    // pass 2 in batches whose bands fit the budget
+    if (hipEventElapsedTime(&ms, d.e0, d.e1) == hipSuccess) { c->fill_ms += ms; c->t_ms[2] = ms; }
+    // pass 2 in batches whose bands fit the budget, IA_NBUF of them in flight, each with its buffer and stream: the tail of
+    // one batch (its longest reads) runs beside the bulk of the next ones
+    const size_t budget = c->mem_budget ? c->mem_budget : (size_t)22 << 30;
+    const size_t WPS = (size_t)((c->WPL + 1) & ~1);
     size_t maxwords = 0;
     std::vector<int> bend;                                                            // batch ends in `order`
     {
         size_t words = 0;
         for (int k = 0; k < nreads; ++k) {
             IaRead &r = hr[order[k]];
-            r.bw = (2 * r.dist) / 32 + 2;
-            const size_t w = (size_t)r.L1 * (size_t)r.bw;
-            if (words && (words + w) * sizeof(uint2) > c->mem_budget) { bend.push_back(k); maxwords = std::max(maxwords, words); words = 0; }
+            r.nl = (2 * r.dist) / (32 * c->WPL) + 2;
+            const size_t w = (size_t)r.L1 * (size_t)r.nl * WPS;
+            if (words && (words + w) * sizeof(uint2) > budget) { bend.push_back(k); maxwords = std::max(maxwords, words); words = 0; }
             r.coff = (long long)words;
-            words += w;
+            words += (w + 15) & ~(size_t)15;                                          // every read's band starts on its own 128-byte line
         }
         bend.push_back(nreads);
         maxwords = std::max(maxwords, words);
     }
-    if (hipMalloc(&d.codes, std::max<size_t>(maxwords, 1) * sizeof(uint2)) != hipSuccess) return PWR_ERR_NOMEM;
+    for (size_t b = 0; b < std::min<size_t>(bend.size(), IA_NBUF); ++b)
+        if (c->codes_cap[b] < maxwords) {                                             // kept for the next call: large allocations are slow
+            (void)hipFree(c->codes[b]); c->codes[b] = nullptr; c->codes_cap[b] = 0;
+            if (hipMalloc(&c->codes[b], std::max<size_t>(maxwords, 1) * sizeof(uint2)) != hipSuccess) return PWR_ERR_NOMEM;
+            c->codes_cap[b] = maxwords;
+        }
     HIPC(hipMemcpyAsync(d.reads, hr.data(), sizeof(IaRead) * nreads, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    const double t_p2 = now_ms();
+    d.ev.resize(2 * bend.size(), nullptr);
+    for (hipEvent_t &e : d.ev) HIPC(hipEventCreate(&e));
     int k0 = 0;
-    for (int k1 : bend) {
-        const int n = k1 - k0;
-        HIPC(hipEventRecord(d.e0, c->stream));
-        launch_bits<1>(c, true, n, d.bases, d.reads, d.order + k0, d.codes);
+    for (size_t bi = 0; bi < bend.size(); ++bi) {
+        const int k1 = bend[bi], n = k1 - k0;
+        hipStream_t st = c->streams[bi % IA_NBUF];
+        HIPC(hipEventRecord(d.ev[2 * bi], st));
+        launch_bits<1>(c, true, n, d.bases, d.reads, d.order + k0, c->codes[bi % IA_NBUF], d.align, st);
         HIPC(hipGetLastError());
-        HIPC(hipEventRecord(d.e1, c->stream));
-        hipLaunchKernelGGL(k_ia_trace, dim3((n + 63) / 64), dim3(64), 0, c->stream, n, d.reads, d.order + k0, d.codes, d.align);
-        HIPC(hipGetLastError());
-        HIPC(hipStreamSynchronize(c->stream));
-        if (hipEventElapsedTime(&ms, d.e0, d.e1) == hipSuccess) c->fill_ms += ms;
+        HIPC(hipEventRecord(d.ev[2 * bi + 1], st));
         k0 = k1;
     }
+    for (hipStream_t st : c->streams) HIPC(hipStreamSynchronize(st));
+    c->t_ms[3] = now_ms() - t_p2;
+    c->t_ms[4] = (double)bend.size();
+    for (size_t bi = 0; bi < bend.size(); ++bi) {
+        if (hipEventElapsedTime(&ms, d.ev[2 * bi], d.ev[2 * bi + 1]) == hipSuccess) c->fill_ms += ms;
+    }
+    const double t_dl = now_ms();
     if (nb) HIPC(hipMemcpyAsync(align + b0, d.align, sizeof(int) * nb, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipMemcpyAsync(hr.data(), d.reads, sizeof(IaRead) * nreads, hipMemcpyDeviceToHost, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
@@ -313,5 +409,7 @@ extern "C" int pia_align(pia_ctx *c, int nreads, const char *bases, const long l
         if (hr[j].dist < 0) return PWR_ERR_INTERNAL;                                  // a traceback left its band: cannot happen
         dist[j] = hr[j].dist;
     }
+    c->t_ms[5] = now_ms() - t_dl;
+    c->t_ms[0] = now_ms() - t_start;
     return PWR_OK;
 }

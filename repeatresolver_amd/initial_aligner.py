@@ -16,9 +16,13 @@ from .realigner import PwrError
 CLI_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "InitialAligner")
 
 
+_LOWER = bytes.maketrans(b"ACGT", b"acgt")
+_DROP = bytes(c for c in range(256) if c not in b"acgtACGT")
+
+
 def _clean(seq: bytes) -> bytes:
     """what ReadingFasta keeps of a sequence (IA:184-201): aAcCgGtT, lower-cased"""
-    return bytes(c for c in seq.lower() if c in b"acgt")
+    return bytes(seq).translate(_LOWER, _DROP)
 
 
 class InitialAligner:
@@ -72,10 +76,18 @@ class InitialAligner:
         if rc:
             raise PwrError(rc, self._lib.pwr_strerror(rc).decode())
 
+    def set_option(self, key: str, value: int):
+        rc = self._lib.pia_set_option(self._h, key.encode(), int(value))
+        if rc:
+            raise PwrError(rc, self._lib.pwr_strerror(rc).decode())
+
     def stats(self):
         cells, ms = ctypes.c_uint64(), ctypes.c_double()
         self._lib.pia_get_stats(self._h, ctypes.byref(cells), ctypes.byref(ms))
-        return {"cells": cells.value, "fill_ms": ms.value}
+        t = (ctypes.c_double * 6)()
+        self._lib.pia_get_timing(self._h, t)
+        return {"cells": cells.value, "fill_ms": ms.value,
+                "last_align_ms": dict(zip(("total", "upload", "pass1", "pass2_and_traceback", "pass2_batches", "download"), t))}
 
 
 def run_files(template_path, reads_path, msa_path=None, class_path=None, cutoff=None, device=None):

@@ -49,9 +49,11 @@ def _mutate(rng, seq, rate):
     return bytes(out)
 
 
-def _check(templ, reads, ia_oracle):
+def _check(templ, reads, ia_oracle, mem_budget=None):
     from repeatresolver_amd.initial_aligner import InitialAligner
     g = InitialAligner(templ)
+    if mem_budget is not None:
+        g.set_option("mem_budget", mem_budget)
     got, dist = g.align(reads)
     st = g.stats()
     g.close()
@@ -155,8 +157,10 @@ def test_longest_template_and_limits(ia_oracle):
     g.close()
 
 
-def test_batches_of_pass_two(ia_oracle, monkeypatch):
-    """many reads in one call, served in launch order longest-first; results come back in the caller's order"""
+@pytest.mark.parametrize("budget", [None, 1 << 16, 1])
+def test_batches_of_pass_two(ia_oracle, budget):
+    """many reads in one call, launched longest-first, pass 2 in one batch / in batches of 64 KB of direction bits / one
+    read per batch; results come back in the caller's order"""
     import random
     rng = random.Random(9)
     templ = bytes(rng.choice(list(b"acgt")) for _ in range(2500))
@@ -164,4 +168,34 @@ def test_batches_of_pass_two(ia_oracle, monkeypatch):
     for k in range(300):
         a = rng.randrange(0, 2300)
         reads.append(_mutate(rng, templ[a:a + rng.randrange(1, 400)], rng.choice([0.0, 0.05, 0.3])))
-    _check(templ, reads, ia_oracle)
+    _check(templ, reads, ia_oracle, budget)
+
+
+def test_pipeline_dataset_to_realigned_msa(tmp_path):
+    """The two GPU steps chained as RepeatResolver.c chains them (InitialAligner -> PW_ReAligner): a simulated data set
+    (DataSimulator's files), the reads cut to their repeat part, aligned into the template on the GPU, the MSA realigned
+    on the GPU -- every file equal to the one the two CPU restatements produce from the same input."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.initial_aligner import run_files
+    from repeatresolver_amd.realigner import run_file
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "port"], check=True, stdout=subprocess.DEVNULL)
+    cfg = dg.SimConfig(kind="Tree", copies=6, coverage=12, difference=0.01, repeat_len=2500, flank=1500, length_scale=0.25,
+                       min_aligned=200, seed=3)
+    prefix = str(tmp_path / "Sim")
+    counts = dg.write_dataset(prefix, cfg)
+    assert counts["cut_reads"] > 20
+    rc, lines = run_files(prefix + "_Template.fasta", prefix + "Seq.fasta", prefix + "_gpu_MSA", prefix + "_gpu_SeqClass")
+    assert rc == 0, lines
+    p = subprocess.run([os.path.join(ROOT, "oracle", "ia_oracle"), prefix + "_Template.fasta", prefix + "Seq.fasta",
+                        prefix + "_cpu_MSA", prefix + "_cpu_SeqClass"])
+    assert p.returncode == 0
+    assert open(prefix + "_gpu_SeqClass").read() == open(prefix + "_cpu_SeqClass").read()
+    msa = open(prefix + "_gpu_MSA", "rb").read()
+    assert msa == open(prefix + "_cpu_MSA", "rb").read() and msa.count(b"\n") > 20
+    rc, lines = run_file(prefix + "_gpu_MSA", prefix + "_gpu_MSAreal", bandwidth=1000, max_rounds=3)
+    assert rc == 0, lines
+    p = subprocess.run([os.path.join(ROOT, "oracle", "pw_oracle"), prefix + "_cpu_MSA", "-o", prefix + "_cpu_MSAreal", "-b", "1000",
+                        "-r", "3"], capture_output=True)
+    assert p.returncode == 0
+    assert open(prefix + "_gpu_MSAreal", "rb").read() == open(prefix + "_cpu_MSAreal", "rb").read()
+    assert [l for l in lines if l.startswith("OverallScore")] == [l for l in p.stdout.decode("latin1").splitlines() if l.startswith("OverallScore")]
