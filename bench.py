@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- sum-of-pairs DP cells/s of the MI355X PW_ReAligner hot path.
 
-The workload is BASELINE.json configs[1]: the DataSimulator-default Tree_1perc_30000kb MSA (100 copies, 40x,
-30 kb; 13 510 rows x 136 477 columns here), resident in HBM when the timed region starts.  One full realignment
+The workload is BASELINE.json configs[1]: the DataSimulator-default Tree_1perc_30000kb data set (100 copies, 40x,
+30 kb), its reads aligned into the template by the InitialAligner (on the GPU, include/pia.h) and stacked into the MSA
+exactly as the reference pipeline does before it calls PW_ReAligner (--input truth: the true alignments stacked
+instead, rounds 1-2's workload); the MSA is resident in HBM when the timed region starts.  One full realignment
 round of it (PW_ReAligner.c:1695-1737) takes tens of seconds, so a "step" is a SLAB of that round: the next
 T/8 rows in input order (pwr_realign_rows, a partial k loop of PW:1695).  Slabs follow each other through the
 round and on into the next rounds, exactly as the reference's loop would visit the rows, so K steps are K/8
@@ -89,6 +91,9 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="tree_default")
+    ap.add_argument("--input", default="pipeline", choices=["pipeline", "truth"],
+                    help="pipeline: the reads aligned into the template by the GPU InitialAligner and stacked by Building_MSA (what the "
+                         "reference feeds PW_ReAligner); truth: the TRUE read-to-template alignments stacked with the same layout rule")
     ap.add_argument("--bandwidth", type=int, default=1000)
     ap.add_argument("--slabs", type=int, default=8, help="steps per realignment round (a step = T/slabs consecutive rows)")
     ap.add_argument("--sections", type=int, default=6, help="N > 1: Window.py parts the MSA is cut into (configs[3]: 6)")
@@ -128,10 +133,17 @@ def main():
     cfg = dg.CONFIGS[args.workload]
     cfg = dg.SimConfig(**{**cfg.__dict__, "seed": args.seed})     # every rank generates the SAME MSA
     t0 = time.time()
-    msa = dg.build_msa(dg.simulate(cfg))
-    rows = [bytes(r) for r in msa]
-    T, W0 = msa.shape
-    del msa
+    if args.input == "pipeline":
+        from repeatresolver_amd.pipeline import initial_msa
+        rows, ia_info = initial_msa(cfg, device=dev)
+        T, W0 = len(rows), len(rows[0])
+        note(f"InitialAligner: {ia_info}")
+    else:
+        msa = dg.build_msa(dg.simulate(cfg))
+        rows = [bytes(r) for r in msa]
+        T, W0 = msa.shape
+        ia_info = None
+        del msa
     gen_s = time.time() - t0
     note(f"generated {T} rows x {W0} columns in {gen_s:.1f} s")
 
@@ -215,13 +227,15 @@ def main():
         traffic, traffic_cmd = measured_traffic()
         score1 = sum(g.total_score() for g in ctxs)
         W1 = sum(g.dims()[1] for g in ctxs)
+        made = ("the reads cut to their repeat part, aligned into the template by the InitialAligner (GPU, placements identical to the reference's) "
+                "and stacked by Building_MSA: the pipeline's real input" if args.input == "pipeline" else
+                "the MSA stacks the TRUE read-to-template alignments with InitialAligner's layout rule -- it is not an InitialAligner product")
         if world == 1:
             wl = (f"{cfg.name} ({args.workload}: {cfg.kind}, {cfg.copies} copies, {cfg.coverage:g}x, {cfg.repeat_len} bp; reads simulated with "
-                  f"DataSimulator.py's distributions, seed {cfg.seed}; the MSA stacks the TRUE read-to-template alignments with InitialAligner's "
-                  f"layout rule -- it is not an InitialAligner product) -> {T} rows x {W0} columns, bandwidth {args.bandwidth}; one step = "
+                  f"DataSimulator.py's distributions, seed {cfg.seed}; {made}) -> {T} rows x {W0} columns, bandwidth {args.bandwidth}; one step = "
                   f"{args.slabs}th of a realignment round = {T // args.slabs} consecutive rows, steps continue through successive rounds")
         else:
-            wl = (f"{cfg.name} as above ({T} rows x {W0} columns, truth-stacked) cut into {args.sections} Window.py sections {bounds}, sections dealt to "
+            wl = (f"{cfg.name} as above ({T} rows x {W0} columns; {made}) cut into {args.sections} Window.py sections {bounds}, sections dealt to "
                   f"{world} ranks by bases; one step = the next {T // args.slabs} rows of every section")
         out = {
             "metric": "sum-of-pairs DP cells/sec",
@@ -241,7 +255,7 @@ def main():
                        "score_before": score0, "score_after": score1,
                        "rows_committed": st["rows_committed"], "rows_recomputed": st["rows_recomputed"], "batches": st["batches"],
                        "rows_changed": st["rows_changed"], "reject_reason": st["reject_reason"],
-                       "generate_s": round(gen_s, 1), "complete": bool(final)},
+                       "generate_s": round(gen_s, 1), "input": args.input, "initial_aligner": ia_info, "complete": bool(final)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic,
