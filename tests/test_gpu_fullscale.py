@@ -97,7 +97,9 @@ def test_config2_pipeline_input_prefix_of_round_one(oracle):
         assert ora.iao_align(r, len(r), templ, len(templ), al, None, codes) == int(dist[j])
         assert list(al) == list(place[j])
         # the row of the MSA holds exactly this read, in order
-    assert rows[0].replace(b"-", b"") == reads[0]
+    assert info["rejected_by_cutoff"] == 0
+    for j in range(0, len(reads), 1):                   # every row holds exactly its read, in order (Building_MSA, IA:602-655)
+        assert rows[j].replace(b"-", b"") == reads[j], j
     _prefix_parity(rows, 16, 96, oracle, others=(700, 13000))
 
 
