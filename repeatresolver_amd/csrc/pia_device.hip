@@ -149,7 +149,8 @@ __global__ __launch_bounds__(64) void k_ia_bits(const uint32_t *__restrict__ tpl
                 // (Measured on the benchmark reads, one batch: pass 2 takes 54 ms without these stores, 84 ms with them; the
                 // traceback behind it adds 4 ms.  Each lane's 128-byte line leaves as eight 16-byte requests, but staging
                 // the lines of a step in LDS so that eight lanes write one line per instruction was slower, 124-140 ms
-                // against 110 ms in nine batches: more registers or eight more LDS writes per lane and step.)
+                // against 110 ms in nine batches: more registers or eight more LDS writes per lane and step; non-temporal
+                // stores 309 ms: the pieces then reach HBM unmerged.)
                 const int rel = lane - band_lane0(rd, x, WPL);
                 if ((unsigned)rel < (unsigned)rd.nl) {
                     uint2 *dst = codes + rd.coff + ((size_t)x * rd.nl + rel) * WPS;
