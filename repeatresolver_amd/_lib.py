@@ -26,6 +26,9 @@ EXPORTS = ["pwr_create", "pwr_destroy", "pwr_trim_ends", "pwr_realign_row", "pwr
 PIA_EXPORTS = ["pia_create", "pia_destroy", "pia_align", "pia_get_stats", "pia_set_option", "pia_get_timing", "pia_read_template", "pia_read_fasta",
                "pia_build_msa", "pia_run_files"]
 
+# every symbol include/pmc.h declares (MaxCorrelation)
+PMC_EXPORTS = ["pmc_maxcorrs", "pmc_last_timing", "pmc_read_msa", "pmc_write", "pmc_run_file"]
+
 _lib = None
 
 
@@ -95,5 +98,13 @@ def load():
     lib.pia_build_msa.restype = ci
     lib.pia_build_msa.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ci, ctypes.c_char_p, ctypes.POINTER(ll), ctypes.POINTER(ci),
                                   ctypes.POINTER(ci), ctypes.c_double, ci]
+    lib.pmc_maxcorrs.restype = ci
+    lib.pmc_maxcorrs.argtypes = [ci, ci, ctypes.c_char_p, ci, ci, ctypes.POINTER(ctypes.c_double)]
+    lib.pmc_last_timing.restype = ci
+    lib.pmc_last_timing.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    lib.pmc_read_msa.restype = ci
+    lib.pmc_read_msa.argtypes = [ctypes.c_char_p, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_void_p)]
+    lib.pmc_write.restype = ci
+    lib.pmc_write.argtypes = [ctypes.c_char_p, ci, ctypes.POINTER(ctypes.c_double)]
     _lib = lib
     return lib

@@ -26,6 +26,11 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.PIA_EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
+    hdr = open(os.path.join(ROOT, "include", "pmc.h")).read()
+    declared = set(re.findall(r"\b(pmc_[a-z_]+)\s*\(", hdr))
+    assert declared == set(_lib.PMC_EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
 
 
 def test_initial_aligner_host_side_needs_no_gpu(tmp_path):
