@@ -108,29 +108,34 @@ __global__ __launch_bounds__(256) void k_mc_end(int W, int sc, int mincov, const
     if (tid < PMC_EI && ii0 + tid < W) jend[ii0 + tid] = s_end[tid];
 }
 
-__device__ __forceinline__ double d_lnchoose(unsigned n, unsigned m)
+// lnf[n] = lgamma(n + 1), n <= rows (made on the host: no count exceeds the number of rows)
+__device__ __forceinline__ double d_lnchoose(const double *__restrict__ lnf, unsigned n, unsigned m)
 {
     if (m == n || m == 0) return 0.0;
-    if (2 * m > n) m = n - m;
-    return lgamma(n + 1.0) - lgamma(m + 1.0) - lgamma(n - m + 1.0);
+    return lnf[n] - lnf[m] - lnf[n - m];
 }
 
-__device__ __forceinline__ double d_hyper_pdf(unsigned k, unsigned n1, unsigned n2, unsigned t)
+__device__ __forceinline__ double d_ln_hyper_pdf(const double *__restrict__ lnf, unsigned k, unsigned n1, unsigned n2, unsigned t)
+{
+    return d_lnchoose(lnf, n1, k) + d_lnchoose(lnf, n2, t - k) - d_lnchoose(lnf, n1 + n2, t);
+}
+
+__device__ __forceinline__ double d_hyper_pdf(const double *__restrict__ lnf, unsigned k, unsigned n1, unsigned n2, unsigned t)
 {
     if (t > n1 + n2) t = n1 + n2;
     if (k > n1 || k > t) return 0.0;
     if (t > n2 && k + n2 < t) return 0.0;
-    return exp(d_lnchoose(n1, k) + d_lnchoose(n2, t - k) - d_lnchoose(n1 + n2, t));
+    return exp(d_ln_hyper_pdf(lnf, k, n1, n2, t));
 }
 
 // gsl_cdf_hypergeometric_Q(k, n1, n2, t) = P(X > k)
-__device__ double d_hyper_Q(unsigned k, unsigned n1, unsigned n2, unsigned t)
+__device__ double d_hyper_Q(const double *__restrict__ lnf, unsigned k, unsigned n1, unsigned n2, unsigned t)
 {
     if (k >= n1 || k >= t) return 0.0;
     const double midpoint = ((double)t * n1) / ((double)n1 + n2);
     if (k < midpoint) {
         unsigned i = k;
-        double s = d_hyper_pdf(i, n1, n2, t), P = s;
+        double s = d_hyper_pdf(lnf, i, n1, n2, t), P = s;
         while (i > 0) {
             s *= (i / (n1 - i + 1.0)) * ((n2 + i - t) / (t - i + 1.0));
             P += s;
@@ -140,7 +145,7 @@ __device__ double d_hyper_Q(unsigned k, unsigned n1, unsigned n2, unsigned t)
         return 1.0 - P;
     }
     unsigned i = k + 1;
-    double s = d_hyper_pdf(i, n1, n2, t), Q = s;
+    double s = d_hyper_pdf(lnf, i, n1, n2, t), Q = s;
     while (i < t) {
         s *= ((n1 - i) / (i + 1.0)) * ((t - i) / (n2 + i + 1.0 - t));
         Q += s;
@@ -151,10 +156,18 @@ __device__ double d_hyper_Q(unsigned k, unsigned n1, unsigned n2, unsigned t)
 }
 
 // MC:413-434 PositiveSignificance (not inlined: the epilogue of k_mc_pairs calls it from an unrolled loop over register arrays)
-__device__ __noinline__ double d_significance(int schnitt, int cov, int gr1, int gr2, int size1, int size2)
+// `floor`: what the two maxima this pair could raise already hold.  The tail is at least its first term, so
+// -log10 pdf(schnitt) bounds the result from above: a pair that cannot raise either maximum is dropped before the sum
+// (after a few thousand partners every variation's maximum is past what chance co-occurrence reaches, and almost every
+// pair ends here -- the sums took 93 % of the kernel before).
+__device__ __noinline__ double d_significance(const double *__restrict__ lnf, int schnitt, int cov, int gr1, int gr2, int size1, int size2, double floor)
 {
     if (gr1 == 0 || gr2 == 0 || schnitt < 1) return 0.0;
-    double Z = -1.0 * log10(d_hyper_Q((unsigned)(schnitt - 1), (unsigned)gr2, (unsigned)(cov - gr2), (unsigned)gr1));
+    if ((unsigned)schnitt <= (unsigned)gr2 && schnitt <= gr1 && gr1 - schnitt <= cov - gr2) {
+        const double zb = d_ln_hyper_pdf(lnf, (unsigned)schnitt, (unsigned)gr2, (unsigned)(cov - gr2), (unsigned)gr1) * -0.43429448190325182;
+        if (zb < floor - 1e-6 && zb < 97.9) return 0.0;               // (beyond 98 the value is 98 + F, which the first term does not bound)
+    }
+    double Z = -1.0 * log10(d_hyper_Q(lnf, (unsigned)(schnitt - 1), (unsigned)gr2, (unsigned)(cov - gr2), (unsigned)gr1));
     if (isinf(Z) || Z > 99) Z = 99.0;
     if (isinf(Z) || Z > 98.0) Z = 98.0 + 2.0 * schnitt / (2.0 * schnitt + (size1 - schnitt) + (size2 - schnitt));     // F_beta(., ., 1), MC:396-410
     return Z;
@@ -166,7 +179,8 @@ struct McTile { int jlo, jhi; };    // positions in the list of relevant j this 
 __global__ __launch_bounds__(PMC_NT) void k_mc_pairs(int W, int sc, int nI, const int *__restrict__ Ivar, const int *__restrict__ Jvar,
                                                      const McTile *__restrict__ tiles, const unsigned long long *__restrict__ G,
                                                      const unsigned long long *__restrict__ LC, const int *__restrict__ gsize,
-                                                     const int *__restrict__ jend, unsigned long long *maxc, unsigned long long *npairs)
+                                                     const int *__restrict__ jend, const double *__restrict__ lnf, unsigned long long *maxc,
+                                                     unsigned long long *npairs)
 {
     __shared__ unsigned long long sG[PMC_TI][PMC_WC], sL[PMC_TI][PMC_WC];
     __shared__ int s_i[PMC_TI];
@@ -204,6 +218,7 @@ __global__ __launch_bounds__(PMC_NT) void k_mc_pairs(int W, int sc, int nI, cons
     }
     if (!have) return;
     const int sj = gsize[j];
+    const double curj = __longlong_as_double((long long)maxc[j]);
     double zj = 0.0;
     unsigned cnt = 0;
 #pragma unroll
@@ -211,7 +226,8 @@ __global__ __launch_bounds__(PMC_NT) void k_mc_pairs(int W, int sc, int nI, cons
         const int i = s_i[a], ii = i / 5;
         if (i >= 0 && jj >= ii + 20 && jj < jend[ii]) {                // MC:798, MC:801-804
             ++cnt;
-            double Z = d_significance(s[a], cv[a], g1[a], g2[a], gsize[i], sj);
+            const double floor = fmin(fmax(curj, zj), __longlong_as_double((long long)maxc[i]));
+            double Z = d_significance(lnf, s[a], cv[a], g1[a], g2[a], gsize[i], sj, floor);
             if (!(Z > 0.0)) Z = 0.0;                                   // (-log10(1) is -0.0, whose bit pattern is the largest of all)
             zj = fmax(zj, Z);
             const unsigned long long zb = (unsigned long long)__double_as_longlong(Z);   // Z >= 0: the bit patterns order like the values
@@ -234,11 +250,11 @@ __global__ __launch_bounds__(PMC_NT) void k_mc_pairs(int W, int sc, int nI, cons
 
 struct McBufs {
     unsigned char *text = nullptr; unsigned long long *G = nullptr, *LC = nullptr, *maxc = nullptr, *npairs = nullptr;
-    int *gsize = nullptr, *cover = nullptr, *jend = nullptr, *Ivar = nullptr, *Jvar = nullptr; McTile *tiles = nullptr;
+    int *gsize = nullptr, *cover = nullptr, *jend = nullptr, *Ivar = nullptr, *Jvar = nullptr; McTile *tiles = nullptr; double *lnf = nullptr;
     ~McBufs()
     {
         (void)hipFree(text); (void)hipFree(G); (void)hipFree(LC); (void)hipFree(maxc); (void)hipFree(npairs); (void)hipFree(gsize);
-        (void)hipFree(cover); (void)hipFree(jend); (void)hipFree(Ivar); (void)hipFree(Jvar); (void)hipFree(tiles);
+        (void)hipFree(cover); (void)hipFree(jend); (void)hipFree(Ivar); (void)hipFree(Jvar); (void)hipFree(tiles); (void)hipFree(lnf);
     }
 };
 
@@ -316,8 +332,12 @@ extern "C" int pmc_maxcorrs(int T, int W, const unsigned char *text, int mincov,
             HIPC(hipMemcpy(d.Ivar, Ivar.data(), (size_t)nI * 4, hipMemcpyHostToDevice));
             HIPC(hipMemcpy(d.Jvar, Jvar.data(), (size_t)nJ * 4, hipMemcpyHostToDevice));
             HIPC(hipMemcpy(d.tiles, tiles.data(), sizeof(McTile) * ntiles, hipMemcpyHostToDevice));
+            std::vector<double> lnf((size_t)T + 2);
+            for (int n = 0; n < T + 2; ++n) lnf[n] = std::lgamma(n + 1.0);
+            if (hipMalloc(&d.lnf, lnf.size() * 8) != hipSuccess) return PWR_ERR_NOMEM;
+            HIPC(hipMemcpy(d.lnf, lnf.data(), lnf.size() * 8, hipMemcpyHostToDevice));
             hipLaunchKernelGGL(k_mc_pairs, dim3(ntiles, (maxspan + PMC_NT - 1) / PMC_NT), dim3(PMC_NT), 0, 0, W, sc, nI, d.Ivar, d.Jvar, d.tiles,
-                               d.G, d.LC, d.gsize, d.jend, d.maxc, d.npairs);
+                               d.G, d.LC, d.gsize, d.jend, d.lnf, d.maxc, d.npairs);
             HIPC(hipGetLastError());
         }
     }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""BASELINE.json's second metric, wall-clock to convergence, for the two GPU steps chained through their drop-in binaries as
-the reference's README chains them:  DataSimulator files -> InitialAligner -> PW_ReAligner (until a round no longer
-improves the score, PW:1681-1754).  usage: pipeline_converge.py [workload] [outdir]  -> one JSON line"""
+"""BASELINE.json's second metric, wall-clock to convergence, for the three GPU steps chained through their drop-in binaries
+as the reference's README chains them:  DataSimulator files -> InitialAligner -> PW_ReAligner (until a round no longer
+improves the score, PW:1681-1754) -> MaxCorrelation.  usage: pipeline_converge.py [workload] [outdir]  -> one JSON line"""
 import json
 import os
 import subprocess
@@ -35,7 +35,14 @@ t_pw = time.time() - t0
 assert p.returncode == 0
 lines = open(log, encoding="latin1").read().splitlines()
 scores = [l for l in lines if l.startswith("OverallScore")]
-print(json.dumps({"workload": wl, "dataset": counts, "simulate_s": round(t_sim, 1),
+t0 = time.time()
+p = subprocess.run([os.path.join(csrc, "MaxCorrelation"), "Sim_MSAreal"], capture_output=True, text=True, cwd=out)
+t_mc = time.time() - t0
+assert p.returncode == 0, p.stdout + p.stderr
+mc_lines = p.stdout.splitlines()
+mc_vals = [float(v) for v in open(os.path.join(out, "MaxCorrsOf_Sim_MSAreal")).read().split()]
+print(json.dumps({"workload": wl, "max_correlation_s": round(t_mc, 1), "max_correlation_stdout": mc_lines,
+                  "maxcorrs": {"n": len(mc_vals), "nonzero": sum(v > 0 for v in mc_vals), "max": max(mc_vals)}, "dataset": counts, "simulate_s": round(t_sim, 1),
                   "initial_aligner_s": round(t_ia, 2), "initial_aligner_stdout": ia_lines,
                   "pw_realigner_s": round(t_pw, 1), "rounds": len(scores) - 2, "score_lines": scores,
                   "dims": [l for l in lines if l.startswith("Rows")], "msa_bytes": os.path.getsize(prefix + "_MSA"),
