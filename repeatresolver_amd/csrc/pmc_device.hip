@@ -5,7 +5,9 @@
 // two columns share at least `mincov` rows (the loop ends at the FIRST column that does not, MC:801-804), four sizes of
 // intersections of row bit sets (MC:421-426) go into one upper tail of a hypergeometric distribution (MC:413-419, GSL);
 // MaxCorrs[i] and MaxCorrs[j] keep the maximum (MC:816-817).
-//   k_mc_bits   the bit sets, word-major: G[w][column * 5 + symbol], LC[w][column]  (MC:340-382), group sizes, coverage
+//   k_mc_bits   the bit sets, word-major: G[w][column * 5 + symbol], LC[w][column]  (MC:340-382), group sizes, coverage;
+//               rows take their bit positions in the order of their first covered column, so that the rows of a column
+//               sit in a narrow range of words (k_mc_colrange) and the products skip the words where a side is all zero
 //   k_mc_end    per column the end of its jj loop
 //   k_mc_pairs  a tiled bit-set product: a tile of PMC_TI relevant variations i stays in LDS (their group and their
 //               column's coverage, a chunk of words at a time), every thread owns one relevant variation j and streams
@@ -44,8 +46,27 @@ __device__ __forceinline__ int code_of(unsigned char ch)
     }
 }
 
-// thread = (column c, word w): 64 rows of one column
-__global__ __launch_bounds__(256) void k_mc_bits(int T, int W, int sc, const unsigned char *__restrict__ text,
+// first covered column of every row (W if it has none): block per row
+__global__ __launch_bounds__(256) void k_mc_rowstart(int W, const unsigned char *__restrict__ text, int *__restrict__ start)
+{
+    __shared__ int s_min;
+    if (threadIdx.x == 0) s_min = W;
+    __syncthreads();
+    const unsigned char *row = text + (size_t)blockIdx.x * W;
+    for (int c0 = 0; c0 < W; c0 += 256) {                            // the start is usually near the row's left end
+        const int c = c0 + threadIdx.x;
+        if (c < W && code_of(row[c]) < 5) atomicMin(&s_min, c);
+        __syncthreads();
+        if (s_min < W) break;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) start[blockIdx.x] = s_min;
+}
+
+// thread = (column c, word w): 64 bit positions of one column.  The rows take their bit positions in the order of their first
+// covered column (inv[position] = row): no count depends on the order, but the rows that cover a column then sit in a narrow
+// range of words, and the products below only visit the words where both sides can be non-zero.
+__global__ __launch_bounds__(256) void k_mc_bits(int T, int W, int sc, const unsigned char *__restrict__ text, const int *__restrict__ inv,
                                                  unsigned long long *__restrict__ G, unsigned long long *__restrict__ LC,
                                                  int *__restrict__ gsize, int *__restrict__ cover)
 {
@@ -53,9 +74,9 @@ __global__ __launch_bounds__(256) void k_mc_bits(int T, int W, int sc, const uns
     if (c >= W) return;
     unsigned long long g[5] = {0, 0, 0, 0, 0};
     for (int r = 0; r < 64; ++r) {
-        const int row = w * 64 + r;
-        if (row >= T) break;
-        const int k = code_of(text[(size_t)row * W + c]);
+        const int pos = w * 64 + r;
+        if (pos >= T) break;
+        const int k = code_of(text[(size_t)inv[pos] * W + c]);
         if (k < 5) g[k] |= 1ull << r;
     }
     unsigned long long lc = 0;
@@ -69,12 +90,27 @@ __global__ __launch_bounds__(256) void k_mc_bits(int T, int W, int sc, const uns
     if (lc) atomicAdd(&cover[c], __popcll(lc));
 }
 
+// the words of a column's coverage set that are not zero: [wlo, whi)
+__global__ __launch_bounds__(256) void k_mc_colrange(int W, int sc, const unsigned long long *__restrict__ LC, int2 *__restrict__ wr)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= W) return;
+    int lo = sc, hi = 0;
+    for (int w = 0; w < sc; ++w)
+        if (LC[(size_t)w * W + c]) { lo = min(lo, w); hi = w + 1; }
+    wr[c] = make_int2(min(lo, hi), hi);
+}
+
 // MC:798-804: jend[ii] = the first jj >= ii + 20 whose column shares fewer than mincov rows with column ii (or W)
-__global__ __launch_bounds__(256) void k_mc_end(int W, int sc, int mincov, const unsigned long long *__restrict__ LC, int *__restrict__ jend)
+__global__ __launch_bounds__(256) void k_mc_end(int W, int sc, int mincov, const unsigned long long *__restrict__ LC, const int2 *__restrict__ wr,
+                                                int *__restrict__ jend)
 {
     extern __shared__ unsigned long long sL[];                         // [PMC_EI][sc]
     __shared__ int s_end[PMC_EI], s_open;
     const int ii0 = blockIdx.x * PMC_EI, tid = threadIdx.x;
+    int wb = sc, we = 0;                                               // the words where any of the block's columns has a row
+    for (int e = 0; e < PMC_EI; ++e)
+        if (ii0 + e < W) { const int2 r = wr[ii0 + e]; if (r.y > r.x) { wb = min(wb, r.x); we = max(we, r.y); } }
     for (int i = tid; i < PMC_EI * sc; i += 256) {
         const int e = i / sc, w = i - e * sc;
         sL[i] = ii0 + e < W ? LC[(size_t)w * W + ii0 + e] : 0ull;
@@ -88,7 +124,7 @@ __global__ __launch_bounds__(256) void k_mc_end(int W, int sc, int mincov, const
 #pragma unroll
         for (int e = 0; e < PMC_EI; ++e) cnt[e] = 0;
         if (jj < W)
-            for (int w = 0; w < sc; ++w) {
+            for (int w = wb; w < we; ++w) {
                 const unsigned long long l = LC[(size_t)w * W + jj];
 #pragma unroll
                 for (int e = 0; e < PMC_EI; ++e) cnt[e] += __popcll(l & sL[e * sc + w]);
@@ -179,33 +215,41 @@ struct McTile { int jlo, jhi; };    // positions in the list of relevant j this 
 __global__ __launch_bounds__(PMC_NT) void k_mc_pairs(int W, int sc, int nI, const int *__restrict__ Ivar, const int *__restrict__ Jvar,
                                                      const McTile *__restrict__ tiles, const unsigned long long *__restrict__ G,
                                                      const unsigned long long *__restrict__ LC, const int *__restrict__ gsize,
-                                                     const int *__restrict__ jend, const double *__restrict__ lnf, unsigned long long *maxc,
-                                                     unsigned long long *npairs)
+                                                     const int *__restrict__ jend, const double *__restrict__ lnf, const int2 *__restrict__ wr,
+                                                     unsigned long long *maxc, unsigned long long *npairs)
 {
     __shared__ unsigned long long sG[PMC_TI][PMC_WC], sL[PMC_TI][PMC_WC];
-    __shared__ int s_i[PMC_TI];
+    __shared__ int s_i[PMC_TI], s_wb, s_we, s_jb, s_je;
     const McTile tl = tiles[blockIdx.x];
     const int b0 = tl.jlo + blockIdx.y * PMC_NT;
     if (b0 >= tl.jhi) return;
     const int tid = threadIdx.x, a0 = blockIdx.x * PMC_TI;
     if (tid < PMC_TI) s_i[tid] = a0 + tid < nI ? Ivar[a0 + tid] : -1;
+    if (tid == 0) { s_wb = sc; s_we = 0; s_jb = sc; s_je = 0; }
     const int b = b0 + tid;
     const bool have = b < tl.jhi;
     const int j = have ? Jvar[b] : 0, jj = j / 5;
+    __syncthreads();
+    // the words where a row can be in a set of the tile's i AND in a set of the block's j (bit positions follow the rows' first
+    // columns, so both are narrow ranges): everything else contributes zero to all four counts
+    if (tid < PMC_TI && s_i[tid] >= 0) { const int2 r = wr[s_i[tid] / 5]; if (r.y > r.x) { atomicMin(&s_wb, r.x); atomicMax(&s_we, r.y); } }
+    if (have) { const int2 r = wr[jj]; if (r.y > r.x) { atomicMin(&s_jb, r.x); atomicMax(&s_je, r.y); } }
+    __syncthreads();
+    const int wbeg = max(s_wb, s_jb), wend = min(s_we, s_je);
     int s[PMC_TI], g1[PMC_TI], g2[PMC_TI], cv[PMC_TI];
 #pragma unroll
     for (int a = 0; a < PMC_TI; ++a) s[a] = g1[a] = g2[a] = cv[a] = 0;
-    for (int w0 = 0; w0 < sc; w0 += PMC_WC) {
+    for (int w0 = wbeg; w0 < wend; w0 += PMC_WC) {
         __syncthreads();
         for (int t = tid; t < PMC_TI * PMC_WC; t += PMC_NT) {
             const int a = t / PMC_WC, w = w0 + t % PMC_WC, i = s_i[a];
-            const bool ok = i >= 0 && w < sc;
+            const bool ok = i >= 0 && w < wend;
             sG[a][t % PMC_WC] = ok ? G[(size_t)w * W * 5 + i] : 0ull;
             sL[a][t % PMC_WC] = ok ? LC[(size_t)w * W + i / 5] : 0ull;
         }
         __syncthreads();
         if (have) {
-            const int wn = min(PMC_WC, sc - w0);
+            const int wn = min(PMC_WC, wend - w0);
             for (int w = 0; w < wn; ++w) {
                 const unsigned long long gj = G[(size_t)(w0 + w) * W * 5 + j], lj = LC[(size_t)(w0 + w) * W + jj];
 #pragma unroll
@@ -251,10 +295,11 @@ __global__ __launch_bounds__(PMC_NT) void k_mc_pairs(int W, int sc, int nI, cons
 struct McBufs {
     unsigned char *text = nullptr; unsigned long long *G = nullptr, *LC = nullptr, *maxc = nullptr, *npairs = nullptr;
     int *gsize = nullptr, *cover = nullptr, *jend = nullptr, *Ivar = nullptr, *Jvar = nullptr; McTile *tiles = nullptr; double *lnf = nullptr;
+    int *start = nullptr, *inv = nullptr; int2 *wr = nullptr;
     ~McBufs()
     {
         (void)hipFree(text); (void)hipFree(G); (void)hipFree(LC); (void)hipFree(maxc); (void)hipFree(npairs); (void)hipFree(gsize);
-        (void)hipFree(cover); (void)hipFree(jend); (void)hipFree(Ivar); (void)hipFree(Jvar); (void)hipFree(tiles); (void)hipFree(lnf);
+        (void)hipFree(cover); (void)hipFree(jend); (void)hipFree(Ivar); (void)hipFree(Jvar); (void)hipFree(tiles); (void)hipFree(lnf); (void)hipFree(start); (void)hipFree(inv); (void)hipFree(wr);
     }
 };
 
@@ -281,17 +326,28 @@ extern "C" int pmc_maxcorrs(int T, int W, const unsigned char *text, int mincov,
     McBufs d;
     if (hipMalloc(&d.text, (size_t)T * W) != hipSuccess || hipMalloc(&d.G, nv * sc * 8) != hipSuccess || hipMalloc(&d.LC, (size_t)W * sc * 8) != hipSuccess ||
         hipMalloc(&d.maxc, nv * 8) != hipSuccess || hipMalloc(&d.gsize, nv * 4) != hipSuccess || hipMalloc(&d.cover, (size_t)W * 4) != hipSuccess ||
-        hipMalloc(&d.jend, (size_t)W * 4) != hipSuccess || hipMalloc(&d.npairs, 8) != hipSuccess) return PWR_ERR_NOMEM;
+        hipMalloc(&d.jend, (size_t)W * 4) != hipSuccess || hipMalloc(&d.npairs, 8) != hipSuccess || hipMalloc(&d.start, (size_t)T * 4) != hipSuccess ||
+        hipMalloc(&d.inv, (size_t)T * 4) != hipSuccess || hipMalloc(&d.wr, (size_t)W * sizeof(int2)) != hipSuccess) return PWR_ERR_NOMEM;
     HIPC(hipMemcpy(d.text, text, (size_t)T * W, hipMemcpyHostToDevice));
     HIPC(hipMemset(d.gsize, 0, nv * 4)); HIPC(hipMemset(d.cover, 0, (size_t)W * 4)); HIPC(hipMemset(d.maxc, 0, nv * 8)); HIPC(hipMemset(d.npairs, 0, 8));
-    hipLaunchKernelGGL(k_mc_bits, dim3((W + 255) / 256, sc), dim3(256), 0, 0, T, W, sc, d.text, d.G, d.LC, d.gsize, d.cover);
+    // bit positions in the order of the rows' first covered columns
+    hipLaunchKernelGGL(k_mc_rowstart, dim3(T), dim3(256), 0, 0, W, d.text, d.start);
+    HIPC(hipGetLastError());
+    std::vector<int> start(T), inv(T);
+    HIPC(hipMemcpy(start.data(), d.start, (size_t)T * 4, hipMemcpyDeviceToHost));
+    for (int r = 0; r < T; ++r) inv[r] = r;
+    std::stable_sort(inv.begin(), inv.end(), [&](int a, int b) { return start[a] < start[b]; });
+    HIPC(hipMemcpy(d.inv, inv.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_mc_bits, dim3((W + 255) / 256, sc), dim3(256), 0, 0, T, W, sc, d.text, d.inv, d.G, d.LC, d.gsize, d.cover);
+    HIPC(hipGetLastError());
+    hipLaunchKernelGGL(k_mc_colrange, dim3((W + 255) / 256), dim3(256), 0, 0, W, sc, d.LC, d.wr);
     HIPC(hipGetLastError());
     std::vector<int> gsize(nv), cover(W), jend(W);
     HIPC(hipMemcpy(gsize.data(), d.gsize, nv * 4, hipMemcpyDeviceToHost));
     HIPC(hipMemcpy(cover.data(), d.cover, (size_t)W * 4, hipMemcpyDeviceToHost));
     const double t1 = now_ms();
     const size_t lds_end = (size_t)PMC_EI * sc * 8;
-    hipLaunchKernelGGL(k_mc_end, dim3((W + PMC_EI - 1) / PMC_EI), dim3(256), lds_end, 0, W, sc, mincov, d.LC, d.jend);
+    hipLaunchKernelGGL(k_mc_end, dim3((W + PMC_EI - 1) / PMC_EI), dim3(256), lds_end, 0, W, sc, mincov, d.LC, d.wr, d.jend);
     HIPC(hipGetLastError());
     HIPC(hipMemcpy(jend.data(), d.jend, (size_t)W * 4, hipMemcpyDeviceToHost));
     const double t2 = now_ms();
@@ -337,7 +393,7 @@ extern "C" int pmc_maxcorrs(int T, int W, const unsigned char *text, int mincov,
             if (hipMalloc(&d.lnf, lnf.size() * 8) != hipSuccess) return PWR_ERR_NOMEM;
             HIPC(hipMemcpy(d.lnf, lnf.data(), lnf.size() * 8, hipMemcpyHostToDevice));
             hipLaunchKernelGGL(k_mc_pairs, dim3(ntiles, (maxspan + PMC_NT - 1) / PMC_NT), dim3(PMC_NT), 0, 0, W, sc, nI, d.Ivar, d.Jvar, d.tiles,
-                               d.G, d.LC, d.gsize, d.jend, d.lnf, d.maxc, d.npairs);
+                               d.G, d.LC, d.gsize, d.jend, d.lnf, d.wr, d.maxc, d.npairs);
             HIPC(hipGetLastError());
         }
     }
