@@ -172,7 +172,7 @@ def test_batches_of_pass_two(ia_oracle, budget):
 
 
 def test_pipeline_dataset_to_realigned_msa(tmp_path):
-    """The two GPU steps chained as RepeatResolver.c chains them (InitialAligner -> PW_ReAligner): a simulated data set
+    """The GPU steps chained as RepeatResolver.c chains them (InitialAligner -> PW_ReAligner -> MaxCorrelation): a simulated data set
     (DataSimulator's files), the reads cut to their repeat part, aligned into the template on the GPU, the MSA realigned
     on the GPU -- every file equal to the one the two CPU restatements produce from the same input."""
     from repeatresolver_amd import datagen as dg
@@ -199,3 +199,14 @@ def test_pipeline_dataset_to_realigned_msa(tmp_path):
     assert p.returncode == 0
     assert open(prefix + "_gpu_MSAreal", "rb").read() == open(prefix + "_cpu_MSAreal", "rb").read()
     assert [l for l in lines if l.startswith("OverallScore")] == [l for l in p.stdout.decode("latin1").splitlines() if l.startswith("OverallScore")]
+    # ... and the step behind: MaxCorrelation on the realigned MSA (floating point: 1e-6 on the printed values)
+    import numpy as np
+    from repeatresolver_amd.max_correlation import run_file as run_mc
+    rc, lines = run_mc("Sim_gpu_MSAreal", mincov=20, cwd=str(tmp_path))
+    assert rc == 0, lines
+    p = subprocess.run([os.path.join(ROOT, "oracle", "mc_oracle"), prefix + "_cpu_MSAreal", prefix + "_cpu_MaxCorrs", "20"])
+    assert p.returncode == 0
+    got = np.array([float(v) for v in open(str(tmp_path / "MaxCorrsOf_Sim_gpu_MSAreal")).read().split()])
+    exp = np.array([float(v) for v in open(prefix + "_cpu_MaxCorrs").read().split()])
+    assert got.shape == exp.shape and (exp > 0).sum() > 50
+    assert np.allclose(got, exp, rtol=0, atol=1.5e-6)
