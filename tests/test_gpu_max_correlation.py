@@ -96,3 +96,27 @@ def test_cli_writes_the_reference_file(tmp_path, mco):
     assert same >= 1990                                               # "%f": rounding may flip a last digit now and then
     rc, lines = run_file("nope", cwd=str(tmp_path))
     assert rc == 1 and lines[-1] == "MA is missing."                 # MC:283
+
+
+def test_row_order_does_not_matter_at_scale():
+    """A size-independent property on a realigned MSA too large for the CPU restatement (2 320 rows x 35 000 columns, 10^9
+    pairs): every count is the size of an intersection of row sets, so shuffling the rows must not change a single bit of
+    the result -- which also exercises the kernels' own reordering of the rows by first column and their word ranges."""
+    import random
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.max_correlation import last_timing, max_correlations
+    from repeatresolver_amd.realigner import PWReAligner
+    rows = [bytes(r) for r in dg.make_msa("tree_medium")]
+    g = PWReAligner(rows, bandwidth=1000)
+    g.trim_ends()
+    g.realign_round()
+    rows = g.export_rows()
+    g.close()
+    a = max_correlations(rows, 30)
+    t = last_timing()
+    assert t["pairs"] > 5e8 and (a > 0).sum() > 10000 and a.max() > 20
+    shuffled = rows[:]
+    random.Random(4).shuffle(shuffled)
+    b = max_correlations(shuffled, 30)
+    assert np.array_equal(a, b)
+    assert last_timing()["pairs"] == t["pairs"]
