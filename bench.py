@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--window", type=int, default=None)
     ap.add_argument("--fill", type=int, default=None, help="DP fill kernel (see include/pwr.h)")
     ap.add_argument("--waves", type=int, default=None)
+    ap.add_argument("--spec-len", type=int, default=None, help="percent a speculative row may be longer than its batch's first row")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--deadline-s", type=float, default=500.0,
                     help="N = 1: once the process has run this long, the line is printed for the steps finished so far (no further step is started)")
@@ -168,6 +169,8 @@ def main():
     score0 = 0
     for _, urows in units:
         g = PWReAligner(urows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, fill=args.fill, waves=args.waves)
+        if args.spec_len is not None:
+            g.set_option("spec_len", args.spec_len)
         g.trim_ends()
         score0 += g.total_score()            # first device call: uploads the MSA into HBM
         ctxs.append(g)

@@ -56,7 +56,7 @@ struct Hdr {                       // lives in device memory, one per context
     int window;
     int fallback;                  // > 0: this many batches are filled by k_fill_v2 (one work-group per job, no waiting across work-groups)
     float ema;                     // running mean of rows committed per batch
-    int pad2;
+    int speclen;                   // a speculative row may be this many percent longer than the batch's first row
     unsigned long long ahead;      // bit b: row next_row + b was committed ahead of an earlier, stale row it commutes with (its band
                                    // interval is disjoint from that row's), so the batches to come leave it out
 };
@@ -2569,7 +2569,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
             if (left > 0) {
                 const int l0 = st.rowlen[rowids[k]];
                 for (int j = 1; j < nb; ++j)
-                    if (st.rowlen[rowids[k + j]] > l0 + l0 / 16 + 64) { nb = j; break; }
+                    if (st.rowlen[rowids[k + j]] > l0 + (int)((long long)l0 * h->speclen / 100) + 64) { nb = j; break; }
             }
             h->nb = nb;
         }
@@ -2667,6 +2667,7 @@ struct pwr_ctx {
     int stall_test = 0;                   // test hook: this many k_fill_v3 launches have their first job stall
     int par_trace = 1;                    // 1: speculative-parallel traceback (k_trace_par), 0: single-wave k_trace_wp
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
+    int spec_len = 6;                     // percent a speculative row may be longer than the first row of its batch (option "spec_len")
     int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP; cross-check and fallback)
     unsigned trace_epoch = 0;             // k_trace_par launch counter (22 bits)
     unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
@@ -3197,11 +3198,12 @@ static int realign_range(pwr_ctx *c, int k0, int n)
         int nb = (int)(c->batch_ema + 2.6);
         nb = std::max(1, std::min(nb, std::min(c->window, n)));
         for (int j = 1; j < nb; ++j)
-            if (c->rowlen[k0 + j] > c->rowlen[k0] + c->rowlen[k0] / 16 + 64) { nb = j; break; }
+            if (c->rowlen[k0 + j] > c->rowlen[k0] + (int)((long long)c->rowlen[k0] * c->spec_len / 100) + 64) { nb = j; break; }
         const float ema0 = (float)c->batch_ema;
         struct { int next_row, row_end, nb, need_grow, window; } init = {k0, kend, nb, 0, c->window};
         static_assert(sizeof(init) == offsetof(Hdr, fallback) - offsetof(Hdr, next_row), "slab fields of Hdr");
         HIPC(hipMemcpyAsync(&c->st.hdr->ema, &ema0, sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIPC(hipMemcpyAsync(&c->st.hdr->speclen, &c->spec_len, sizeof(int), hipMemcpyHostToDevice, c->stream));
         HIPC(hipMemcpyAsync(&c->st.hdr->next_row, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
         HIPC(hipMemsetAsync(&c->st.hdr->ahead, 0, sizeof(unsigned long long), c->stream));
         HIPC(hipStreamSynchronize(c->stream));                                 // (init lives on the stack)
@@ -3359,6 +3361,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     // window beyond what one CU-full of jobs survives is of no use anyway)
     if (!strcmp(key, "window")) { if (value < 1 || value > 128 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
     if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
+    if (!strcmp(key, "spec_len")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->spec_len = (int)value; return PWR_OK; }
     if (!strcmp(key, "fill")) { if (c->on_device || (value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "stall_test")) { if (value < 0 || value > 1000000) return PWR_ERR_ARG; c->stall_test = (int)value; return PWR_OK; }
     if (!strcmp(key, "evcap")) { if (value < 0 || value > EVCAP) return PWR_ERR_ARG; c->evcap = (int)value; c->jb.evcap = (int)value; return PWR_OK; }
@@ -3377,6 +3380,7 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     if (!c || !key || !value) return PWR_ERR_ARG;
     if (!strcmp(key, "window")) *value = c->window;
     else if (!strcmp(key, "profile")) *value = c->profile;
+    else if (!strcmp(key, "spec_len")) *value = c->spec_len;
     else if (!strcmp(key, "fill")) *value = c->fill_mode;
     else if (!strcmp(key, "ptrace")) *value = c->par_trace;
     else if (!strcmp(key, "force64")) *value = c->force64;
