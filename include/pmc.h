@@ -27,7 +27,8 @@ extern "C" {
 /* Parallel_AllMaxCorrsRechner(threads, 0, siglength, mincov, signumber, cutoff) (MC:839-905) on text = rows x width
  * characters (a c g t A C G T, '-' or '_' = gap, anything else = not covered, MC:303-330): maxcorrs[width * 5]. */
 int pmc_maxcorrs(int rows, int width, const unsigned char *text, int mincov, int device, double *maxcorrs);
-/* Duration of the last pmc_maxcorrs' device work, ms: [0] all, [1] bit sets, [2] ranges (MC:801), [3] pairs; [4] pairs evaluated. */
+/* Duration of the last pmc_maxcorrs' device work, ms: [0] all, [1] bit sets, [2] ranges (MC:801), [3] pairs; [4] pairs evaluated.
+ * (Kept per process, not per call: meaningful when pmc_maxcorrs is not called from several threads at once.) */
 int pmc_last_timing(double *ms5);
 
 /* ---- host side, plain C (pmc_host.c) ---- */
