@@ -210,3 +210,16 @@ def test_pipeline_dataset_to_realigned_msa(tmp_path):
     exp = np.array([float(v) for v in open(prefix + "_cpu_MaxCorrs").read().split()])
     assert got.shape == exp.shape and (exp > 0).sum() > 50
     assert np.allclose(got, exp, rtol=0, atol=1.5e-6)
+
+
+def test_reads_longer_than_the_template(ia_oracle):
+    """reads several times the template's length (most bases stay unaligned, the distance exceeds the template, the stored
+    band is wider than the wave's 64 lanes), next to short ones in the same call"""
+    import random
+    rng = random.Random(12)
+    templ = bytes(rng.choice(list(b"acgt")) for _ in range(500))
+    reads = [bytes(rng.choice(list(b"acgt")) for _ in range(3000)), templ * 3, _mutate(rng, templ, 0.1),
+             bytes(rng.choice(list(b"ac")) for _ in range(1200)), templ[100:160]]
+    _check(templ, reads, ia_oracle)
+    templ2 = bytes(rng.choice(list(b"acgt")) for _ in range(2300))           # two words per lane
+    _check(templ2, [bytes(rng.choice(list(b"acgt")) for _ in range(5000)), templ2 + templ2[:700]], ia_oracle)
