@@ -96,7 +96,8 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
  * work-group per pipeline wave; 3 = k_fill_v2: one work-group per DP, the independent cross-check and fallback, see
  * DESIGN.md 3.2), "waves" (waves per DP of the wave-pipeline fills: 9 (default), 8, 5, 4, 3, or 17 with k_fill_v3 only;
  * bandwidths above 1000 always use 9), "ptrace" (1 = speculative-parallel traceback k_trace_par, the default; 0 = one
- * wave per job), "slack" (spare column capacity kept when the device arrays are (re)allocated).  "fill", "waves" and
+ * wave per job), "slack" (spare column capacity kept when the device arrays are (re)allocated), "spec_len" (percent a
+ * speculative row may be longer than the first row of its batch, default 6; results do not depend on it).  "fill", "waves" and
  * "slack" must be set before the first call that touches the device. */
 int pwr_set_option(pwr_ctx *ctx, const char *key, long value);
 int pwr_get_option(pwr_ctx *ctx, const char *key, long *value);
