@@ -60,6 +60,9 @@ typedef struct pwr_stats {
     uint64_t rows_ahead;        /* commits that went ahead of a stale row of their batch (the two rows commute: disjoint band intervals) */
     uint64_t rows_wide;         /* committed realignments whose scores were not provably below 2^30 and that the 64-bit fill
                                    (the reference's own arithmetic, PW:30, PW:271) computed */
+    uint64_t seg_jobs;          /* fills that ran as several segments side by side (k_fill_v3) */
+    uint64_t segs;              /* ... and the segments they were cut into */
+    uint64_t seg_fails;         /* ... of which this many failed the check of a segment's start and were repeated in one piece */
 } pwr_stats;
 
 /* Replaces MMA_Einlesen (PW:93-241) for an in-memory matrix: `text` holds rows*width characters,
@@ -97,8 +100,10 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
  * DESIGN.md 3.2), "waves" (waves per DP of the wave-pipeline fills: 9 (default), 8, 5, 4, 3, or 17 with k_fill_v3 only;
  * bandwidths above 1000 always use 9), "ptrace" (1 = speculative-parallel traceback k_trace_par, the default; 0 = one
  * wave per job), "slack" (spare column capacity kept when the device arrays are (re)allocated), "spec_len" (percent a
- * speculative row may be longer than the first row of its batch, default 6; results do not depend on it).  "fill", "waves" and
- * "slack" must be set before the first call that touches the device. */
+ * speculative row may be longer than the first row of its batch, default 6; results do not depend on it), "seg_rows" / "seg_max" /
+ * "warm_pct" (k_fill_v3 fills a DP as up to seg_max segments of about seg_rows rows side by side, each warmed up while the band
+ * moves by warm_pct percent of the bandwidth, and checks every one; seg_rows 0 = in one piece; results do not depend on them).
+ * "fill", "waves", "slack" and the three "seg" options must be set before the first call that touches the device. */
 int pwr_set_option(pwr_ctx *ctx, const char *key, long value);
 int pwr_get_option(pwr_ctx *ctx, const char *key, long *value);
 int pwr_get_stats(pwr_ctx *ctx, pwr_stats *out);

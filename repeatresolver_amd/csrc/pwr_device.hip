@@ -47,6 +47,7 @@ struct Hdr {                       // lives in device memory, one per context
     unsigned long long rows_wide;      // committed realignments that were filled by k_fill64
     unsigned long long stalls;         // k_fill_v3 jobs given up because a wave waited too long for its neighbour
     unsigned long long rows_ahead;     // commits that went ahead of a stale row of the same batch
+    unsigned long long seg_jobs, segs, seg_fails;   // segmented fills: jobs cut into more than one segment, their segments, jobs whose check failed
     int agree, pad0;               // the two order buffers hold the same ordinals for the columns [0, agree)
     // the k loop (PW:1695) is sequenced on the device: a batch realigns the rows rowids[next_row ...], its commit kernel moves
     // next_row on and sizes the next batch, so the host enqueues batches without waiting for their outcome
@@ -59,6 +60,7 @@ struct Hdr {                       // lives in device memory, one per context
     int speclen;                   // a speculative row may be this many percent longer than the batch's first row
     unsigned long long ahead;      // bit b: row next_row + b was committed ahead of an earlier, stale row it commutes with (its band
                                    // interval is disjoint from that row's), so the batches to come leave it out
+    int noseg_row, pad1;           // this row's segmented fill failed its check: its next fill runs in one piece (-1: none)
 };
 
 struct Tally {                     // 32 B per column slot
@@ -67,7 +69,7 @@ struct Tally {                     // 32 B per column slot
     uint32_t pad;
 };
 
-struct JobMeta {                   // 80 B
+struct JobMeta {                   // 88 B
     int k, L, lo, hi, W, entry, ok, nnew;
     unsigned maxS;
     int ver;                       // hdr->version when the job's inputs were gathered
@@ -79,6 +81,7 @@ struct JobMeta {                   // 80 B
     int active;                    // 0: the job slot is unused in this batch (everything else is left from the last use)
     int wide;                      // 1: the scores may not fit 32 bits: k_fill64 fills this job, the wave pipeline skips it
     int off, pad;                  // the job's row is rowids[next_row + off]
+    int nseg, segfail;             // segments the fill was cut into (k_fill_v3); 1: a segment's warm-up had not converged, the job is repeated in one piece
 };
 
 struct DState {
@@ -104,6 +107,21 @@ struct DState {
     int *newidx;                   // scratch [colcap]
 };
 
+// A DP is filled in SEGMENTS that run side by side (k_fill_v3): segment s owns the DP rows [xown, xe) and starts WARM rows
+// earlier, at xb, from the free start of PW:265 (as if row xb were the row's first base).  The fill is a min-plus recurrence
+// whose row vectors forget where they started: after the band has moved past the columns of the start row they are PARALLEL to
+// the true ones (equal up to one additive constant over the whole band), and from there on every comparison the traceback
+// record is made of comes out the same.  Whether the warm-up got there is CHECKED, not assumed (k_seg_check compares the
+// scores of row xown - 1 as the segment has them with those its predecessor ends on); a job that fails is filled again in
+// one piece.  (Rank convergence of tropical DP; measured for this band: scripts/dev/rank_convergence.py.)
+#define SEG_MAX 32
+struct SegDesc {
+    int job, s;                    // job slot, index of the segment within the job
+    int xb, xown, xe;              // warm-up from xb, own rows [xown, xe)
+    int fin, active;               // the job's last segment (holds the DP's last row); 0: slot unused in this launch
+    int grow0;                     // row of the job's mailbox area (gmb) that holds the segment's row xb
+    unsigned long long cells;      // DP cells of the rows [xb, xe)
+};
 struct GatherPart;
 struct JobBufs {
     GatherPart *gpart;             // [njobs][GATHER_G] partial results of the gather's shares
@@ -119,7 +137,11 @@ struct JobBufs {
     uint4 *desc;                   // [njobs][Lmax]   per DP row: {anf | base << 24, flags of waves 0-7, 8-15, 16-23} (4 bits per wave)
     int wpNW, wpMS;                // geometry of the wave pipeline the descriptors are made for
     unsigned *lastM;               // [njobs][NC]     scores of the last DP row (wave-pipeline fill)
-    unsigned long long *gmb;       // [njobs][NW][Lmax][2] k_fill_v3: {P_end, tag}, {M_last, tag} per wave and DP row
+    unsigned long long *gmb;       // [njobs][NW][gstride][2] k_fill_v3: {P_end, tag}, {M_last, tag} per wave and DP row (segments side by side)
+    SegDesc *seg;                  // [njobs][SEG_MAX] plan of the fill (k_gather_b)
+    unsigned *chk;                 // [njobs][SEG_MAX + 1][2][NC] scores of the row before segment s: [0] as s has them after its warm-up, [1] as s - 1 ends
+    int smax, seg_rows, warm_cols; // at most smax segments per job, of about seg_rows own rows, warmed up over warm_cols columns of band movement
+    int gstride;                   // rows per wave of a job's mailbox area
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
     unsigned long long *gtr;       // [njobs][TRK]    k_trace_par: hand-over words of the chunks
     unsigned trace_tag;            // 22-bit launch tag of those words
@@ -331,10 +353,73 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, c
     }
 }
 
-// gather, step b: the row's own symbols marked in the interval (bases of the share's rows; blank runs between segments: 7)
+// The plan of a job's fill (one work-group): how many segments, where each starts to warm up, the cells it computes.
+// Own parts start at multiples of 64 rows (the fill works in blocks of 64 rows and stores its record per 16); a warm-up
+// starts at the last multiple of 64 whose band lies at least warm_cols columns left of the own part's first band.
+__device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
+{
+    __shared__ int s_x[SEG_MAX + 1], s_xb[SEG_MAX], s_S;
+    __shared__ unsigned long long s_cells[SEG_MAX];
+    const int tid = threadIdx.x;
+    JobMeta *m = &jb.meta[job];
+    SegDesc *sg = jb.seg + (size_t)job * SEG_MAX;
+    if (!m->active || m->L <= 0) { if (tid < SEG_MAX) sg[tid].active = 0; return; }
+    const int L = m->L, W = m->W, B = st.B, H = st.H;
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    if (tid == 0) {
+        int S = 1;
+        if (jb.seg_rows > 0 && st.hdr->noseg_row != m->k) S = (L + jb.seg_rows / 2) / jb.seg_rows;
+        S = max(1, min(S, min(jb.smax, L / 128)));
+        s_S = S;
+        m->nseg = S; m->segfail = 0;
+    }
+    if (tid < SEG_MAX) s_cells[tid] = 0;
+    __syncthreads();
+    const int S = s_S;
+    if (tid <= S) s_x[tid] = tid == S ? L : (int)(((long long)L * tid / S) & ~63ll);
+    __syncthreads();
+    if (tid < S) {
+        int xb = 0;
+        if (tid > 0) {
+            // largest multiple of 64 below x_s whose row sits at least warm_cols columns left of row x_s (Way[] is increasing)
+            const int xs = s_x[tid], lim = way[xs] - jb.warm_cols;
+            int a = 0, b = xs / 64 - 1;                       // candidates 64 * [0, b]
+            if (way[0] > lim) b = -1;
+            while (a < b) { const int mid = (a + b + 1) >> 1; if (way[64 * mid] <= lim) a = mid; else b = mid - 1; }
+            xb = b < 0 ? 0 : 64 * a;
+        }
+        s_xb[tid] = xb;
+    }
+    __syncthreads();
+    for (int s2 = 0; s2 < S; ++s2) {
+        unsigned long long cs = 0;
+        for (int x = s_xb[s2] + tid; x < s_x[s2 + 1]; x += GATHER_NT) cs += (unsigned long long)min(B, W - max(0, way[x] - H));
+        for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o);
+        if ((tid & 63) == 0 && cs) atomicAdd(&s_cells[s2], cs);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int grow = 0;
+        for (int s2 = 0; s2 < SEG_MAX; ++s2) {
+            SegDesc d;
+            d.job = job; d.s = s2; d.active = s2 < S ? 1 : 0;
+            d.xb = d.xown = d.xe = 0; d.fin = 0; d.grow0 = 0; d.cells = 0;
+            if (s2 < S) {
+                d.xb = s_xb[s2]; d.xown = s_x[s2]; d.xe = s_x[s2 + 1]; d.fin = s2 == S - 1 ? 1 : 0;
+                d.grow0 = grow; d.cells = s_cells[s2];
+                grow += d.xe - d.xb;
+            }
+            sg[s2] = d;
+        }
+    }
+}
+
+// gather, step b: the row's own symbols marked in the interval (bases of the share's rows; blank runs between segments: 7);
+// the share after the last one plans the job's fill
 __global__ __launch_bounds__(GATHER_NT) void k_gather_b(DState st, JobBufs jb)
 {
     const int job = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    if (g == GATHER_G) { plan_segments(st, jb, job); return; }
     const JobMeta *m = &jb.meta[job];
     if (!m->active || m->L <= 0) return;
     const int L = m->L, k = m->k, lo = m->lo;
@@ -988,14 +1073,27 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     __shared__ __attribute__((aligned(16))) int ldsS1[2][4][MS];
     __shared__ unsigned long long rP[V4_RB], rM[V4_RB];                  // the neighbour's {P_end, tag}, {M_last, tag}
     __shared__ int wprog, wdone;                                         // worker's progress (rows), worker finished
-    const int job = blockIdx.x + 8 * blockIdx.z, lane = threadIdx.x & 63;
+    // virtual job = (job, segment): segment s of job j is slot j * smax + s, so the segments of a job spread over the XCDs
+    const int vjob = blockIdx.x + 8 * blockIdx.z, lane = threadIdx.x & 63;
     const int role = UNI((int)threadIdx.x >> 6);                          // 0 worker, 1 fetcher
     const int wave = blockIdx.y;
-    if (job >= jb.njobs_launched) return;
+    if (vjob >= jb.njobs_launched * jb.smax) return;
+    const int job = vjob / jb.smax;
+    const SegDesc *const sd = jb.seg + (size_t)job * SEG_MAX + (vjob % jb.smax);
     JobMeta *m = &jb.meta[job];
-    const int L = UNI(m->L);
     if (st.hdr->fallback > 0) return;                                             // k_fill_v2 stands in (after a stall)
-    if (!m->active || L <= 0 || !m->ok || m->wide) return;
+    if (!m->active || m->L <= 0 || !m->ok || m->wide || !sd->active) return;
+    // The segment is a DP of its own on the rows [xb, xe) of the job: x below counts from xb, and everything indexed by DP
+    // row is addressed from there.  Its first row starts free (PW:265) whether it is the row's first base or not; its last
+    // row is the DP's last row (PW:1386, entry scan) only in the job's last segment.
+    const int seg_xb = UNI(sd->xb), seg_fin = UNI(sd->fin);
+    const int L = UNI(sd->xe) - seg_xb;
+    const int Lf = seg_fin ? L - 1 : L;                                           // rows below Lf are ordinary rows
+    const int x_own = UNI(sd->xown) - seg_xb;                                     // rows below it are the warm-up: nothing of them is kept
+    const int g_own = x_own >> 4;
+    const int chkA = x_own > 0 ? x_own : -1, chkB = seg_fin ? -1 : L;            // after these rows' predecessors the scores are left for the check
+    unsigned *const chk_w = jb.chk + (((size_t)job * (SEG_MAX + 1) + sd->s) * 2 + 0) * (size_t)jb.NC;       // [s][0]: this segment after its warm-up
+    unsigned *const chk_t = jb.chk + (((size_t)job * (SEG_MAX + 1) + sd->s + 1) * 2 + 1) * (size_t)jb.NC;   // [s + 1][1]: what the next one must match
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
     if (threadIdx.x < V4_RB) { rP[threadIdx.x] = 0; rM[threadIdx.x] = 0; }
     if (threadIdx.x == 0) { wprog = 0; wdone = 0; }
@@ -1003,12 +1101,13 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 
     const int wl = (wave + NW - 1) % NW;
     const unsigned tagbase = jb.tagbase;
-    unsigned long long *const gmy = jb.gmb + ((size_t)job * NW + wave) * (size_t)jb.Lmax * 2;
-    const unsigned long long *const gleftw = jb.gmb + ((size_t)job * NW + wl) * (size_t)jb.Lmax * 2;
+    const size_t gstride = (size_t)jb.gstride;
+    unsigned long long *const gmy = jb.gmb + (((size_t)job * NW + wave) * gstride + (size_t)sd->grow0) * 2;
+    const unsigned long long *const gleftw = jb.gmb + (((size_t)job * NW + wl) * gstride + (size_t)sd->grow0) * 2;
     // Ptot(r), the minimum of the whole DP row r (the virtual extension of PW:285-295 is G + Ptot): it is the P_end word of
     // the wave that holds the band's last macro-strip in row r -- read straight from there, on the rare occasions it is needed
-    const unsigned long long *const gjob = jb.gmb + (size_t)job * NW * (size_t)jb.Lmax * 2;
-#define PTOT_PTR(AP, BP, R) (gjob + (((size_t)((((AP) + (BP) - 1 - lo) / MS) % NW)) * (size_t)jb.Lmax + (size_t)(R)) * 2)
+    const unsigned long long *const gjob = jb.gmb + ((size_t)job * NW * gstride + (size_t)sd->grow0) * 2;
+#define PTOT_PTR(AP, BP, R) (gjob + (((size_t)((((AP) + (BP) - 1 - lo) / MS) % NW)) * gstride + (size_t)(R)) * 2)
     int *const abortf = &m->abort;
 #define GLD(PTR) __hip_atomic_load((PTR), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GST(PTR, VAL, ROW) __hip_atomic_store((PTR), ((unsigned long long)(tagbase | (unsigned)((ROW) + 1)) << 32) | (unsigned)(VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -1045,10 +1144,10 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 
     // ---- worker
     const int lo = UNI(m->lo), hi = UNI(m->hi), W = UNI(m->W), B = st.B, H = st.H;
-    const int *way = jb.way + (size_t)job * jb.Lmax;
-    const uint8_t *seq = st.seq + st.rowoff[UNI(m->k)];
+    const int *way = jb.way + (size_t)job * jb.Lmax + seg_xb;
+    const uint8_t *seq = st.seq + st.rowoff[UNI(m->k)] + seg_xb;
     const int4 *rec2 = jb.rec2 + (size_t)job * jb.colcap * 2;
-    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+    uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride + (size_t)(seg_xb >> 4) * RS;
     unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
     const int lc = lane * C;
 #define V4_LOADS(MSX, SLOT, AU, AG, AI, GL)                                                      \
@@ -1069,7 +1168,9 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     int ug[C], gg[C], ig[C];
     int nu[C], ng[C], ni[C];
     int gleft = 0, gleftn = 0;
-    int ms = wave, msn = wave + NW;
+    // the wave's first macro-strip: the first one of its residue class that is not left of the first row's band
+    const int ms_first = (max(0, UNI(way[0]) - H) - lo) / MS;
+    int ms = ms_first + (((wave - ms_first) % NW) + NW) % NW, msn = ms + NW;
     int cs = 0;
     V4_LOADS(ms, 0, ug, gg, ig, gleft)
     V4_LOADS(msn, 1, nu, ng, ni, gleftn)
@@ -1082,7 +1183,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     int x = 0, blk = 0;
     int wcur = way[min(lane, L - 1)], scur = seq[min(lane, L - 1)];
     int wnxt = way[min(64 + lane, L - 1)], snxt = seq[min(64 + lane, L - 1)];
-    const uint4 *desc = jb.desc + (size_t)job * jb.Lmax;
+    const uint4 *desc = jb.desc + (size_t)job * jb.Lmax + seg_xb;
     const int fsh = 4 * (wave & 7);
     const unsigned *descw = (const unsigned *)desc + 1 + (wave >> 3);      // this wave's flag word of a descriptor
     unsigned dca = desc[min(lane, L - 1)].x, dcf = descw[4 * min(lane, L - 1)] >> fsh;
@@ -1090,6 +1191,15 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     int a = max(0, __builtin_amdgcn_readlane(wcur, 0) - H), a_prev = 0, Bx_prev = 0;
     int sx = __builtin_amdgcn_readlane(scur, 0);
 
+    // the scores of the row just done, for k_seg_check: band cells of this wave's macro-strip, indexed like lastM
+#define V4_CHK_STORE(XNEXT, AF, BEND)                                                            \
+    if ((XNEXT) == chkA || (XNEXT) == chkB) {                                                    \
+        unsigned *cv_ = (XNEXT) == chkA ? chk_w : chk_t;                                         \
+        _Pragma("unroll") for (int i = 0; i < C; ++i) {                                          \
+            const int y_ = lo + ms * MS + lc + i;                                                \
+            cv_[wave * MS + lc + i] = (y_ >= (AF) && y_ < (BEND)) ? Mprev[i] : 0xffffffffu;      \
+        }                                                                                        \
+    }
 #define V4_ALIGN_ACC(WANT)                                                                       \
     if (nacc != (WANT)) {                                                                        \
         const int sh_ = (WANT) - nacc;                                                           \
@@ -1100,7 +1210,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     if (gacc >= 0) {                                                                             \
         V4_ALIGN_ACC(16)                                                                         \
         uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;                \
-        _Pragma("unroll") for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; } \
+        _Pragma("unroll") for (int i = 0; i < C; ++i) { if (gacc >= g_own) d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; } \
         gacc = -1; nacc = 0;                                                                     \
     }
 #define V4_ROTATE_BLOCK()                                                                        \
@@ -1137,7 +1247,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         const unsigned long long mf_ = early_hi < b0_ + 64 ? 1ull << (early_hi - b0_) : 0ull;    \
         bOm |= me_ | mf_; bMm |= me_ | mf_; bPm |= me_; bTm |= me_;                              \
     }
-    bool dead = jb.stall_test && job == 0 && wave == 0;                           // (test hook: as if the neighbour never answered)
+    bool dead = jb.stall_test && vjob == 0 && wave == 0;                          // (test hook: as if the neighbour never answered)
     int first_pending = 0;                                                       // row x is the wave's first on its macro-strip: the fast path takes it
     int early_lo = 0, early_hi = -1;                                             // rows [early_lo, early_hi) run ahead of the strip's first row with work, early_hi
     while (x < L && !dead) {
@@ -1154,7 +1264,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         // anything else (a change of role inside the group, a partial group) takes the same code with run-time flags.
         // All roles must cost about the same: a wave that is slower than its neighbour while it is the band's last strip
         // falls behind for good, and every row of lag per hop is paid NW - 1 times per lap of the ring (measured).
-        if ((ran_prev || first_pending) && x < L - 1) {
+        if ((ran_prev || first_pending) && x < Lf) {
             unsigned long long bOm = __builtin_amdgcn_ballot_w64((dcf & 1u) != 0);
             const bool first = UNI(first_pending) != 0;
             if (first || ((bOm >> (x & 63)) & 1ull)) {
@@ -1241,7 +1351,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 while (true) {
                     const int r_beg = x & 15, g0 = x - r_beg, r0 = g0 & 63;
                     int nrun = __builtin_ctz(~((unsigned)(bOm >> (r0 + r_beg)) & 0xffffu) | (1u << (16 - r_beg)));   // ordinary rows from x on, within the group
-                    nrun = min(nrun, L - 1 - x);
+                    nrun = min(nrun, Lf - x);
                     if (nrun <= 0) break;
                     const unsigned nPm = (unsigned)(bPm >> r0) & 0xffffu, kMm = (unsigned)(bMm >> r0) & 0xffffu, eTm = (unsigned)(bTm >> r0) & 0xffffu;
                     // the rows from x on that play the same role as row x: one stretch
@@ -1399,10 +1509,11 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     if ((x & 15) == 0) {                                          // the 16-row group is complete
                         uint32_t *d_ = dirs + (size_t)gacc * RS + (size_t)wave * MS + (size_t)lc;
 #pragma unroll
-                        for (int i = 0; i < C; ++i) { d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; }
+                        for (int i = 0; i < C; ++i) { if (gacc >= g_own) d_[i] = accA[i] | (accC[i] << 16); accA[i] = accC[i] = 0; }
                         gacc = -1; nacc = 0;
+                        V4_CHK_STORE(x, af_done, min(af_done + B, W))
                     } else nacc = x & 15;
-                    if (dead || x >= L - 1) break;
+                    if (dead || x >= Lf) break;
                     if ((x >> 6) != blk) {
                         V4_ROTATE_BLOCK()
                         bOm = __builtin_amdgcn_ballot_w64((dcf & 1u) != 0); bPm = __builtin_amdgcn_ballot_w64((dcf & 2u) != 0);
@@ -1460,7 +1571,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             const int xn = min(wm ? x + __builtin_ctzll(wm) : ((x >> 6) + 1) << 6, L);     // (> x: row x itself has no work)
             // (take the strip over at the group boundary before xn, see V4_EARLY_MASKS; the fast path starts it)
             int xs = xn;
-            if (wm && xn < L - 1) {
+            if (wm && xn < Lf) {
                 xs = max(x, xn & ~15);
                 if (xs < 1) xs = xn;
                 early_lo = xs; early_hi = xn;
@@ -1481,7 +1592,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             }
             continue;
         }
-        if (!ran_prev && x > 0 && x < L - 1) { first_pending = 1; continue; }     // first row on this macro-strip: the fast path takes it
+        if (!ran_prev && x > 0 && x < Lf) { first_pending = 1; continue; }        // first row on this macro-strip: the fast path takes it
         const int y0 = lo + ms * MS;
         const int yq = y0 - 1;
         const bool needP = ms > ms_lo;
@@ -1546,7 +1657,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         const int excl = __builtin_amdgcn_update_dpp(PWR_BIG, incl, DPP_WAVE_SHR1, 0xF, 0xF, false);
         const int P_end = min(P_in, __builtin_amdgcn_readlane(incl, 63));
         int p = min(P_in, excl);
-        if (x != L - 1) {
+        if (x != Lf) {
 #pragma unroll
             for (int i = 0; i < C; ++i) {
                 accA[i] = (accA[i] << 1) | ((tg[i] >= p) ? 1u : 0u);
@@ -1554,6 +1665,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 Mprev[i] = (rel0 + i < 0) ? PWR_INF : (unsigned)(gg[i] + p);
             }
         } else {
+            // (the DP's last row: only the job's last segment gets here with x == Lf)
             unsigned Mn[C];
             unsigned fa = 0;
 #pragma unroll
@@ -1579,6 +1691,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             GST(gmy + 2 * (size_t)x + 1, Mprev[C - 1], x);
         }
         ran_prev = 1;
+        V4_CHK_STORE(x + 1, a, a + Bx)
         V4_NEXT_ROW()
     }
     V4_FLUSH()
@@ -1600,11 +1713,14 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         return;
     }
     if (wave == 0 && lane == 0) {
-        m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
-        m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
-        m->rounds = 0;
-        atomicAdd(&st.hdr->cells_computed, m->cells);
+        if (sd->s == 0) {
+            m->clk = (unsigned)(__builtin_amdgcn_s_memtime() - t_clk0);
+            m->rclk = (unsigned)(__builtin_amdgcn_s_memrealtime() - t_real0);
+            m->rounds = 0;
+        }
+        atomicAdd(&st.hdr->cells_computed, sd->cells);
     }
+#undef V4_CHK_STORE
 #undef V4_EARLY_MASKS
 #undef PTOT_PTR
 #undef GLD
@@ -1618,6 +1734,49 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 #undef V4_FLUSH
 #undef V4_ROTATE_BLOCK
 #undef V4_NEXT_ROW
+}
+
+// ---------------------------------------------------------------------------------------------
+// The check behind the segmented fill: segment s (s > 0) started from the free start some hundred rows before its own part;
+// its record is the true one iff, in the row before its own part, its scores are PARALLEL to the ones segment s - 1 ends on:
+// the same cells unreachable (>= PWR_INF) and one and the same difference in every other cell of the band -- a min-plus
+// recurrence maps parallel rows to parallel rows, and every bit of the record compares two candidates of one row.  (By
+// induction the scores segment s - 1 ends on are themselves parallel to the true ones.)  One work-group per (job, s); the
+// entries are consumed (set to "not written"), so a store that went missing can never pass for a match.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_seg_check(DState st, JobBufs jb)
+{
+    __shared__ int s_min[4], s_max[4], s_bad;
+    const int job = blockIdx.x, s = blockIdx.y + 1, tid = threadIdx.x;
+    JobMeta *m = &jb.meta[job];
+    if (!m->active || m->L <= 0 || !m->ok || m->wide || m->abort || st.hdr->fallback > 0) return;
+    if (s >= m->nseg) return;
+    const SegDesc *sd = jb.seg + (size_t)job * SEG_MAX + s;
+    const int xr = sd->xown - 1;                                                   // the row both segments have
+    const int lo = m->lo, W = m->W, B = st.B, H = st.H, RS = jb.NC;
+    const int a = max(0, jb.way[(size_t)job * jb.Lmax + xr] - H), Bx = min(B, W - a);
+    unsigned *cw = jb.chk + (((size_t)job * (SEG_MAX + 1) + s) * 2 + 0) * (size_t)jb.NC;
+    unsigned *ct = jb.chk + (((size_t)job * (SEG_MAX + 1) + s) * 2 + 1) * (size_t)jb.NC;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    int dmin = INT_MAX, dmax = INT_MIN, bad = 0;
+    for (int j = tid; j < Bx; j += 256) {
+        const int idx = (a + j - lo) % RS;
+        const unsigned vw = cw[idx], vt = ct[idx];
+        cw[idx] = 0xffffffffu; ct[idx] = 0xffffffffu;
+        if (vw == 0xffffffffu || vt == 0xffffffffu) bad = 1;                       // a band cell nobody stored
+        else if ((vw >= PWR_INF) != (vt >= PWR_INF)) bad = 1;
+        else if (vw < PWR_INF) { const int d = (int)(vw - vt); dmin = min(dmin, d); dmax = max(dmax, d); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { dmin = min(dmin, __shfl_xor(dmin, o)); dmax = max(dmax, __shfl_xor(dmax, o)); }
+    if ((tid & 63) == 0) { s_min[tid >> 6] = dmin; s_max[tid >> 6] = dmax; }
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (tid == 0) {
+        const int lo_ = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3])), hi_ = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        if (s_bad || (lo_ != INT_MAX && lo_ != hi_)) m->segfail = 1;
+        if (s == 1) { atomicAdd(&st.hdr->seg_jobs, 1ull); atomicAdd(&st.hdr->segs, (unsigned long long)m->nseg); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1801,7 +1960,7 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
     const int job = blockIdx.x, lane = threadIdx.x;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok || m->abort) return;
+    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail) return;
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -1968,7 +2127,7 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
     const unsigned ttag = jb.trace_tag;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok || m->abort) return;
+    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail) return;
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -2521,6 +2680,13 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
                 stopped = true;
                 continue;
             }
+            if (m->segfail) {
+                // a segment of its fill had not forgotten its start when its own rows began (k_seg_check): the row is
+                // realigned again, its fill in one piece
+                if (threadIdx.x == 0) { h->seg_fails += 1; h->noseg_row = m->k; }
+                stopped = true;
+                continue;
+            }
             bool good = validate_job(st, jb, j, sh, s_i);                         // (on success lo / hi are in today's numbering)
             if (good && nskip > 0) {
                 order_c = cur_order(st);
@@ -2539,6 +2705,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
                 continue;
             }
             commit_job(st, jb, j, sh, s_i, &evs);
+            if (threadIdx.x == 0 && h->noseg_row == m->k) h->noseg_row = -1;
             live_done += 1;
             if (nskip > 0) ahead_n += 1;
             if (m->wide && threadIdx.x == 0) h->rows_wide += 1;
@@ -2672,6 +2839,9 @@ struct pwr_ctx {
     unsigned trace_epoch = 0;             // k_trace_par launch counter (22 bits)
     unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
     int wp_waves = 9;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane
+    int seg_rows = 1024;                  // k_fill_v3: a DP is filled in segments of about this many rows, side by side (0: in one piece)
+    int seg_max = 16;                     // ... at most this many per DP (<= SEG_MAX)
+    int warm_pct = 200;                   // ... each warmed up while the band moves by this many percent of the bandwidth
     // stats
     pwr_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -2844,8 +3014,16 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     jb.wpNW = c->wp_waves;
     jb.wpMS = 64 * wpC;
     if ((rc = dmalloc(c, &jb.lastM, (size_t)njobs * jb.NC))) return rc;
+    jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
+    jb.seg_rows = c->fill_mode == 4 ? c->seg_rows : 0;
+    jb.warm_cols = (int)std::min<long long>((long long)c->B * c->warm_pct / 100 + 2, 1 << 20);
+    jb.gstride = jb.Lmax + jb.smax * (jb.warm_cols + 64);
+    if ((rc = dmalloc(c, &jb.seg, (size_t)njobs * SEG_MAX))) return rc;
+    if (hipMemsetAsync(jb.seg, 0, sizeof(SegDesc) * (size_t)njobs * SEG_MAX, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
+    if ((rc = dmalloc(c, &jb.chk, (size_t)njobs * (SEG_MAX + 1) * 2 * NC))) return rc;
+    if (hipMemsetAsync(jb.chk, 0xff, sizeof(unsigned) * (size_t)njobs * (SEG_MAX + 1) * 2 * NC, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     if (c->fill_mode == 4) {
-        const size_t nmb = (size_t)njobs * c->wp_waves * jb.Lmax * 2;
+        const size_t nmb = (size_t)njobs * c->wp_waves * jb.gstride * 2;
         if ((rc = dmalloc(c, &jb.gmb, nmb))) return rc;
         // on the stream the kernels run on (a plain hipMemset is not ordered against it) and waited for
         if (hipMemsetAsync(jb.gmb, 0, nmb * 8, c->stream) != hipSuccess ||
@@ -2867,7 +3045,7 @@ static void free_jobs(pwr_ctx *c)
 {
     JobBufs &jb = c->jb;
     dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.g64); dfree(c, jb.gpart); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
-    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.gtr); dfree(c, jb.diag); dfree(c, c->d_jobrows);
+    dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.seg); dfree(c, jb.chk); dfree(c, jb.gtr); dfree(c, jb.diag); dfree(c, c->d_jobrows);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -2946,7 +3124,7 @@ static int upload(pwr_ctx *c)
     st.slotcap = st.colcap;
     int rc;
     Hdr hdr{};
-    hdr.W = W; hdr.nslots = W; hdr.nfree = 0; hdr.cur = 0; hdr.agree = 0;
+    hdr.W = W; hdr.nslots = W; hdr.nfree = 0; hdr.cur = 0; hdr.agree = 0; hdr.noseg_row = -1;
     long long *d_rowoff; int *d_rowlen; uint8_t *d_seq;
     if ((rc = dmalloc(c, &st.hdr, 1))) return rc;
     if ((rc = dmalloc(c, &d_rowoff, T + 1))) return rc;
@@ -3074,7 +3252,7 @@ static int launch_fill(pwr_ctx *c, int njobs)
         // one work-group (worker + fetcher wave) per wave of the pipeline; grid.x = 8 keeps the work-groups of a DP
         // on one XCD (work-groups go to the XCDs round-robin by linear id)
         if (++c->fill_epoch >= (1u << 15)) {
-            const size_t nmb = (size_t)c->njobs * c->wp_waves * c->jb.Lmax * 2;
+            const size_t nmb = (size_t)c->njobs * c->wp_waves * c->jb.gstride * 2;
             HIPC(hipMemsetAsync(c->jb.gmb, 0, nmb * 8, c->stream));
             c->fill_epoch = 1;
         }
@@ -3082,7 +3260,7 @@ static int launch_fill(pwr_ctx *c, int njobs)
         c->jb.njobs_launched = njobs;
         c->jb.stall_test = c->stall_test > 0 ? 1 : 0;
         if (c->stall_test > 0) c->stall_test -= 1;
-        const dim3 grid(8, c->wp_waves, (njobs + 7) / 8);
+        const dim3 grid(8, c->wp_waves, (njobs * c->jb.smax + 7) / 8);     // one slot per (job, segment)
         if (c->wp_waves == 17) hipLaunchKernelGGL((k_fill_v3<17, 1>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3>), grid, dim3(128), 0, c->stream, c->st, c->jb);
@@ -3091,6 +3269,8 @@ static int launch_fill(pwr_ctx *c, int njobs)
         else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v3<9, 2>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_v3<9, 4>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         c->jb.stall_test = 0;
+        if (c->jb.smax > 1 && c->jb.seg_rows > 0)
+            hipLaunchKernelGGL(k_seg_check, dim3(njobs, c->jb.smax - 1), dim3(256), 0, c->stream, c->st, c->jb);
     }
     // k_fill_v2: the fill of its own right (option fill = 3), or the stand-in behind k_fill_v3 that only runs while
     // Hdr::fallback > 0, i.e. after a k_fill_v3 job gave up waiting for a neighbour work-group
@@ -3141,6 +3321,7 @@ static void stats_from_hdr(pwr_ctx *c, const Hdr &h)
     c->stats.rows_wide = h.rows_wide;
     c->stats.stalls = h.stalls;
     c->stats.rows_ahead = h.rows_ahead;
+    c->stats.seg_jobs = h.seg_jobs; c->stats.segs = h.segs; c->stats.seg_fails = h.seg_fails;
     for (int i = 0; i < 4; ++i) c->stats.reject_reason[i] = h.fail_reason[i];
 }
 
@@ -3162,7 +3343,7 @@ static int enqueue_batch(pwr_ctx *c)
     int rc;
     c->jb.gather_tag = ++c->gather_tag;
     hipLaunchKernelGGL(k_gather_a, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids);
-    hipLaunchKernelGGL(k_gather_b, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
+    hipLaunchKernelGGL(k_gather_b, dim3(n, GATHER_G + 1), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
     hipLaunchKernelGGL(k_gather_c, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
     if ((rc = launch_fill(c, n))) return rc;
     hipLaunchKernelGGL(k_fill64, dim3(n), dim3(F64_NT), 0, c->stream, c->st, c->jb);       // jobs the gather flagged wide (none, normally)
@@ -3371,6 +3552,9 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     // (test hooks: where the launch counters behind the mailbox / hand-over tags stand, so that their wrap-around can be exercised)
     if (!strcmp(key, "fill_epoch")) { if (value < 0 || value >= (1 << 15)) return PWR_ERR_ARG; c->fill_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "trace_epoch")) { if (value < 0 || value >= (1 << 22)) return PWR_ERR_ARG; c->trace_epoch = (unsigned)value; return PWR_OK; }
+    if (!strcmp(key, "seg_rows")) { if (c->on_device || value < 0 || value > 1000000) return PWR_ERR_ARG; c->seg_rows = (int)value; return PWR_OK; }
+    if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
+    if (!strcmp(key, "warm_pct")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->warm_pct = (int)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9 && value != 17)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
     return PWR_ERR_ARG;
 }
@@ -3386,6 +3570,9 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "force64")) *value = c->force64;
     else if (!strcmp(key, "slack")) *value = c->cap_slack;
     else if (!strcmp(key, "waves")) *value = c->wp_waves;
+    else if (!strcmp(key, "seg_rows")) *value = c->seg_rows;
+    else if (!strcmp(key, "seg_max")) *value = c->seg_max;
+    else if (!strcmp(key, "warm_pct")) *value = c->warm_pct;
     else return PWR_ERR_ARG;
     return PWR_OK;
 }
@@ -3415,7 +3602,7 @@ extern "C" int pwr_reset_stats(pwr_ctx *c)
     if (c->on_device) {
         if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
         HIPC(hipStreamSynchronize(c->stream));
-        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 13 * sizeof(unsigned long long)));
+        HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 16 * sizeof(unsigned long long)));
     }
     return PWR_OK;
 }

@@ -24,7 +24,7 @@ def _check(code, what):
 class PWReAligner:
     """One MSA resident on one GPU.  rows: list of equal-length bytes over `acgtACGT-_ `."""
 
-    def __init__(self, rows, bandwidth=1000, device=0, window=None, profile=False, fill=None, waves=None, slack=None):
+    def __init__(self, rows, bandwidth=1000, device=0, window=None, profile=False, fill=None, waves=None, slack=None, **options):
         self._lib = _lib.load()
         self._h = ctypes.c_void_p()
         self.T = len(rows)
@@ -43,6 +43,8 @@ class PWReAligner:
             _check(self._lib.pwr_set_option(self._h, b"fill", int(fill)), "set fill")
         if profile:
             _check(self._lib.pwr_set_option(self._h, b"profile", 1), "set profile")
+        for key, value in options.items():           # any other knob of pwr_set_option (include/pwr.h), e.g. seg_rows
+            _check(self._lib.pwr_set_option(self._h, key.encode(), int(value)), "set " + key)
 
     def set_option(self, key, value):
         """pwr_set_option (include/pwr.h); most knobs must be set before the first call that touches the device."""
