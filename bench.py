@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_CELL = 4.0           # algorithmic bytes per DP cell (one 32-bit score per cell)
-FILL_KERNELS = {5: "k_fill_sk", 4: "k_fill_v3", 3: "k_fill_v2"}
+FILL_KERNELS = {4: "k_fill_v3", 3: "k_fill_v2"}
 
 
 def measured_traffic():
@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--fill", type=int, default=None, help="DP fill kernel (see include/pwr.h)")
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--spec-len", type=int, default=None, help="percent a speculative row may be longer than its batch's first row")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="any other knob of pwr_set_option (include/pwr.h), e.g. seg_rows=512")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--deadline-s", type=float, default=500.0,
                     help="N = 1: once the process has run this long, the line is printed for the steps finished so far (no further step is started)")
@@ -168,7 +169,8 @@ def main():
     ctxs = []
     score0 = 0
     for _, urows in units:
-        g = PWReAligner(urows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, fill=args.fill, waves=args.waves)
+        g = PWReAligner(urows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, fill=args.fill, waves=args.waves,
+                        **{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.opt})
         if args.spec_len is not None:
             g.set_option("spec_len", args.spec_len)
         g.trim_ends()
@@ -206,7 +208,8 @@ def main():
     def report(steps_done, dt, final):
         """Builds and prints THE json line (rank 0)."""
         st = stats_sum() if ctxs else {"cells_reference": 0, "cells_computed": 0, "fill_ms": 0.0, "fill_launches": 0, "fill_launches_timed": 0,
-                                       "rows_committed": 0, "rows_recomputed": 0, "batches": 0, "rows_changed": 0, "reject_reason": [0, 0, 0, 0]}
+                                       "rows_committed": 0, "rows_recomputed": 0, "batches": 0, "rows_changed": 0, "reject_reason": [0, 0, 0, 0],
+                                       "stalls": 0, "rows_wide": 0, "rows_ahead": 0, "seg_jobs": 0, "segs": 0, "seg_fails": 0}
         cells = float(st["cells_reference"])
         tmax, csum, tmin = dt, cells, dt
         per_rank = None
@@ -258,6 +261,12 @@ def main():
                        "score_before": score0, "score_after": score1,
                        "rows_committed": st["rows_committed"], "rows_recomputed": st["rows_recomputed"], "batches": st["batches"],
                        "rows_changed": st["rows_changed"], "reject_reason": st["reject_reason"],
+                       # self-audit: a time-out repeated by the stand-in kernel, a 64-bit fill or a failed segment check would show here
+                       "stalls": st["stalls"], "rows_wide": st["rows_wide"], "rows_ahead": st["rows_ahead"],
+                       "useful_frac": (st["cells_reference"] / st["cells_computed"]) if st["cells_computed"] else None,
+                       "commits_per_batch": (st["rows_committed"] / st["batches"]) if st["batches"] else None,
+                       "seg_jobs": st["seg_jobs"], "segs": st["segs"], "seg_fails": st["seg_fails"],
+                       "options": {k_: ctxs[0].get_option(k_) for k_ in ("window", "fill", "waves", "spec_len", "seg_rows", "seg_max", "warm_pct")} if ctxs else None,
                        "generate_s": round(gen_s, 1), "input": args.input, "initial_aligner": ia_info, "complete": bool(final)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

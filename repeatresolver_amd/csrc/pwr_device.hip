@@ -61,7 +61,15 @@ struct Hdr {                       // lives in device memory, one per context
     unsigned long long ahead;      // bit b: row next_row + b was committed ahead of an earlier, stale row it commutes with (its band
                                    // interval is disjoint from that row's), so the batches to come leave it out
     int noseg_row, pad1;           // this row's segmented fill failed its check: its next fill runs in one piece (-1: none)
+    unsigned long long dbg[32];    // phase timers of commit and trace (10 ns ticks), only written by builds with -DPWR_DIAG
 };
+#ifdef PWR_DIAG
+#define PH_T0() unsigned long long ph_t_ = __builtin_amdgcn_s_memrealtime();
+#define PH_ADD(H, I) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); if (threadIdx.x == 0) (H)->dbg[I] += n_ - ph_t_; ph_t_ = n_; }
+#else
+#define PH_T0()
+#define PH_ADD(H, I)
+#endif
 
 struct Tally {                     // 32 B per column slot
     uint32_t w[6];                 // PW:46 w_con
@@ -114,7 +122,7 @@ struct DState {
 // record is made of comes out the same.  Whether the warm-up got there is CHECKED, not assumed (k_seg_check compares the
 // scores of row xown - 1 as the segment has them with those its predecessor ends on); a job that fails is filled again in
 // one piece.  (Rank convergence of tropical DP; measured for this band: scripts/dev/rank_convergence.py.)
-#define SEG_MAX 32
+#define SEG_MAX 64
 struct SegDesc {
     int job, s;                    // job slot, index of the segment within the job
     int xb, xown, xe;              // warm-up from xb, own rows [xown, xe)
@@ -2141,6 +2149,10 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
     const int x_lo = wv * Lc, x_top = min(L, x_lo + Lc) - 1;
     const bool top = (wv == nch - 1);
 
+#ifdef PWR_DIAG
+    const unsigned long long tr_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tr_t1 = 0, tr_t2 = 0;
+#endif
     int yguess = 0, yout_guess = 0, xrec_lo = x_top + 1;    // rows [xrec_lo, x_top] were recorded in phase 0
     int cnt = 0;                                            // 'up' moves (new columns) of the chunk as it stands
     int err = 0;
@@ -2183,6 +2195,9 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
             if (top) break;                                 // already final
             unsigned long long hw = 0;
             int f = 0;
+#ifdef PWR_DIAG
+            tr_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
             for (int spin = 0; spin < TR_SPIN_LIMIT; ++spin) {
                 hw = __hip_atomic_load(&hand[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 f = (UNI((unsigned)(hw >> 42)) == ttag) ? (int)(UNI((unsigned)(hw >> 40)) & 3u) : 0;
@@ -2190,6 +2205,9 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
                 __builtin_amdgcn_s_sleep(2);
             }
             if (f != 1) { err = 5; break; }                 // the chunk above failed (or timed out)
+#ifdef PWR_DIAG
+            tr_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
             y = (int)(UNI((unsigned)hw) & 0xffffffu) - 1;
             if (y == yguess && xrec_lo <= x_lo) break;      // the guess was right and the whole chunk is recorded
             check_merge = true;
@@ -2329,6 +2347,13 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
         if (lane == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
         return;
     }
+#ifdef PWR_DIAG
+    if (job == 0 && lane == 0 && (wv == 0 || top)) {
+        const unsigned long long n_ = __builtin_amdgcn_s_memrealtime();
+        unsigned long long *d_ = st.hdr->dbg + (top ? 20 : 16);
+        d_[0] += (top ? n_ : tr_t1) - tr_t0; d_[1] += tr_t2 - tr_t1; d_[2] += n_ - (top ? n_ : tr_t2); d_[3] += 1;
+    }
+#endif
     if (wv == 0 && lane == 0) {
         int tot = cnt;
         for (int c = 1; c < nch; ++c)                       // all chunks above are final (hand-over order) and posted
@@ -2381,6 +2406,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     const int nfree = h->nfree, nslots = h->nslots;
     const int take = min(nnew, nfree);
     const unsigned newver = (unsigned)h->version + 1u;
+    PH_T0()
     if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[3] = 0; s_i[4] = 0x7fffffff; s_i[5] = 0; }   // [0] freed slots, [1] some column lost its last base, [3] any change, [4] first ordinal that changes, [5] structural events
     for (int y = ny0 + tid; y <= nyL; y += COMMIT_NT) mark2[y - lo] = 0;
     __syncthreads();
@@ -2389,6 +2415,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         if (!(c & 1)) mark2[(c >> 1) - lo] = (uint8_t)(st.seq[off + x] + 1);
     }
     __syncthreads();
+    PH_ADD(h, 1)
     // 1. new columns (PW:1245-1332) and the slot of every base.  The tallies of the neighbour column y
     //    are read as the trace saw them: the row's old symbol taken out, the new one not yet put in.
     unsigned carry = 0;
@@ -2430,6 +2457,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         }
     }
     __syncthreads();
+    PH_ADD(h, 2)
     // 2. Columns_Downdater + Column_Updater fused (PW:1172-1243): only columns whose symbol for this
     //    row really changes are touched (and stamped with the new version)
     const int u0 = min(way0, ny0), u1 = max(wayL, nyL);
@@ -2454,6 +2482,8 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
             }
         }
     }
+    __syncthreads();
+    PH_ADD(h, 3)
     for (int x = tid; x < L; x += COMMIT_NT) st.pos[off + x] = aux[x];
     __syncthreads();
     if (tid == 0) {
@@ -2468,6 +2498,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         __syncthreads();
         if (tid == 0 && nb) st.nbrk[k] = 0;
     }
+    PH_ADD(h, 4)
     const bool restructure = (nnew > 0) || (s_i[1] != 0);
     const int nev = s_i[5];
     const bool inplace = restructure && nev <= jb.evcap;
@@ -2585,6 +2616,10 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         if (s_i[3] || nnew > 0) h->rows_changed += 1;
     }
     __syncthreads();
+    PH_ADD(h, 5)
+#ifdef PWR_DIAG
+    if (tid == 0) { h->dbg[6] += 1; h->dbg[7] += (unsigned long long)nev; h->dbg[8] += inplace ? 1 : 0; }
+#endif
 }
 
 // Is a speculatively computed job still exact?  Its DP inputs are: the tallies of the columns
@@ -2595,7 +2630,7 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
 __device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_i)
 {
     const int tid = threadIdx.x;
-    const Hdr *h = st.hdr;
+    Hdr *h = st.hdr;
     JobMeta *m = &jb.meta[job];
     const int W = h->W;
     const int *order = h->cur ? st.order1 : st.order0;
@@ -2603,6 +2638,7 @@ __device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsig
     int *way = jb.way + (size_t)job * jb.Lmax;
     int *newcol = jb.newcol + (size_t)job * jb.Lmax;
     if (m->ver == h->version) return true;                     // nothing committed since the gather
+    PH_T0()
     const int lo = m->lo, hi = m->hi;
     const int lo2 = st.rank[m->slot_lo], hi2 = st.rank[m->slot_hi];
     bool ok = lo2 >= 0 && lo2 < W && hi2 >= 0 && hi2 < W;
@@ -2631,6 +2667,10 @@ __device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsig
     }
     if (ok && tid == 0) m->W = W;
     __syncthreads();
+    PH_ADD(h, 0)
+#ifdef PWR_DIAG
+    if (tid == 0) h->dbg[9] += 1;
+#endif
     return ok;
 }
 
@@ -2645,6 +2685,9 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
     __shared__ int s_i[8];
     __shared__ CommitEv evs;
     Hdr *h = st.hdr;
+#ifdef PWR_DIAG
+    const unsigned long long ph_chain0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x == 0) { h->ncommitted = 0; h->stop = 0; }
     __syncthreads();
     if (h->status != 0 || h->need_grow) return;
@@ -2740,6 +2783,9 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
             }
             h->nb = nb;
         }
+#ifdef PWR_DIAG
+        h->dbg[10] += __builtin_amdgcn_s_memrealtime() - ph_chain0; h->dbg[11] += 1;
+#endif
     }
 }
 
@@ -3651,6 +3697,17 @@ extern "C" int pwr_debug_rounds(pwr_ctx *c)
     JobMeta m;
     if (hipMemcpy(&m, c->jb.meta, sizeof m, hipMemcpyDeviceToHost) != hipSuccess) return PWR_ERR_DEVICE;
     return m.rounds;
+}
+
+// phase timers of commit and trace (dev builds with -DPWR_DIAG): 32 words, 10 ns ticks and counts; reading clears them
+extern "C" int pwr_debug_phase_times(pwr_ctx *c, unsigned long long *out)
+{
+    if (!c || !c->on_device || !out) return PWR_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpy(out, c->st.hdr->dbg, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost));
+    HIPC(hipMemset(c->st.hdr->dbg, 0, sizeof(unsigned long long) * 32));
+    return PWR_OK;
 }
 
 // shader clock the fill kernel of job 0 ran at: delta s_memtime / delta s_memrealtime (100 MHz)
