@@ -151,8 +151,9 @@ struct JobBufs {
     int smax, seg_rows, warm_cols; // at most smax segments per job, of about seg_rows own rows, warmed up over warm_cols columns of band movement
     int gstride;                   // rows per wave of a job's mailbox area
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
-    unsigned long long *gtr;       // [njobs][TRK]    k_trace_par: hand-over words of the chunks
-    unsigned trace_tag;            // 22-bit launch tag of those words
+    unsigned long long *gtr;       // [njobs][trk]    k_trace_par / k_trace_blk: hand-over words of the chunks
+    int trk;                       // ... per job: max(TRK, Lmax / 64 + 1)
+    unsigned trace_tag;            // 14-bit launch tag of those words
     long long *g64;                // [njobs][colcap] k_fill64: 64-bit prefix sums of S(.,4)
     int force64;                   // test hook: every job takes the 64-bit fill
     int evcap;                     // commits with more structural events than this renumber by a pass over the width (test hook; <= EVCAP)
@@ -2131,7 +2132,7 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
 {
     const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int wv = UNI((int)blockIdx.y * TRW + (tid >> 6));
-    unsigned long long *const hand = jb.gtr + (size_t)job * TRK;
+    unsigned long long *const hand = jb.gtr + (size_t)job * jb.trk;
     const unsigned ttag = jb.trace_tag;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
@@ -2360,6 +2361,290 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
             tot += (int)((__hip_atomic_load(&hand[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 24) & 0xffffull);
         m->nnew = tot;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trace, one wave per 64-row block ("chunk"), hand-over without a chain.  As in k_trace_par every chunk but the top one
+// first traces its rows from a GUESSED arrival column (just left of where the row above sits now) and records, per row,
+// the arrival column and the placement; it then posts a word {arrival column it started from, exit column, 'up' moves}.
+// What k_trace_par resolves top-down, one chunk after the other (a chain of L / 192 hand-overs, a third of its time), every
+// chunk settles here for itself, from the words of the chunks above it:
+//   * whenever the exit the chunk above posts differs from the arrival a chunk has traced from, it retraces from there
+//     (until it arrives at a recorded row in the column the record arrived in: the recorded steps below are then the true
+//     ones) and posts again -- all chunks whose guess was wrong do that at the same time, each trusting the exit above it;
+//   * a chunk is FINAL once the chunks above it form a consistent chain -- each one's arrival equal to the exit posted by
+//     the chunk above it -- up to a chunk that is final (the top chunk is, from the start: it begins in the entry column).
+//     A step of the trace is a function of (row, column), so a record traced from the true arrival is the true record,
+//     whatever else its chunk may post later; by induction down the chain every exit in it is the true one.
+// A chunk only ever waits for a chunk above it, and retraces only when an exit above it has changed, which ends with the top
+// chunk's.  Results are those of k_trace_wp bit for bit.
+// word: [63:50] launch tag, [49:48] 1 provisional / 2 final / 3 error, [47:41] 'up' moves, [40:21] arrival + 1, [20:0] exit + 1
+// (exit field all ones: the pass broke off inside the chunk)
+// ---------------------------------------------------------------------------------------------
+#define TB_W 4                                          // chunks per work-group
+#define TB_BROKE 0x1fffffu
+#define TB_WORD(TAG, FLAG, CNT, ARR, EXF) (((unsigned long long)((TAG) & 0x3fffu) << 50) | ((unsigned long long)(FLAG) << 48) | ((unsigned long long)((CNT) & 0x7f) << 41) | \
+                                           ((unsigned long long)(((ARR) + 1) & 0xfffff) << 21) | (unsigned long long)((EXF) & 0x1fffffu))
+#define TB_MAXCOL ((1 << 20) - 4)                       // columns the word can name
+__global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
+{
+    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    JobMeta *m = &jb.meta[job];
+    const int L = UNI(m->L);
+    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail) return;
+    const int nch = (L + 63) >> 6;
+    // the top chunks first: they are the ones everybody else waits for
+    const int c = nch - 1 - UNI((int)blockIdx.y * TB_W + (tid >> 6));
+    if (c < 0) return;
+    unsigned long long *const hand = jb.gtr + (size_t)job * jb.trk;
+    const unsigned ttag = jb.trace_tag & 0x3fffu;
+    const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
+    const int *way = jb.way + (size_t)job * jb.Lmax;
+    const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
+    const unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
+    int *newcol = jb.newcol + (size_t)job * jb.Lmax;
+    int *yin = jb.aux + (size_t)job * jb.Lmax;             // arrival column per row (aux is rewritten by the commit later)
+    const int x_lo = c << 6, x_top = min(L, x_lo + 64) - 1;
+    const bool top = c == nch - 1;
+    const int wcur = way[min(x_lo + lane, L - 1)];         // Way[] of the chunk's rows, one per lane
+    int ncreg = 0, yireg = 0;                              // the chunk's record, one row per lane
+    int xrec_lo = x_top + 1;                               // rows [xrec_lo, x_top] are recorded
+    int cnt = 0, err = 0, yexit = 0;
+    bool broke = false;                                    // the last pass from the top of the chunk did not reach its bottom
+
+    // one pass over the chunk's rows from arrival column y0: records as it goes; with check_merge it stops as soon as it
+    // arrives at a recorded row in the column the record arrived in (the recorded steps below are then the true ones)
+    auto pass = [&](int y0, const bool check_merge, bool &merged) __attribute__((always_inline)) {
+        int x = x_top, y = y0;
+        int gcur = -1, yb = 0;
+        uint32_t win[4] = {0, 0, 0, 0};
+        int gpre = -1, ybpre = 0;
+        uint32_t pre[4] = {0, 0, 0, 0};
+        merged = false;
+        int e = 0;
+        while (x >= x_lo && !e) {
+            x = UNI(x); y = UNI(y); gcur = UNI(gcur); yb = UNI(yb); gpre = UNI(gpre); ybpre = UNI(ybpre); cnt = UNI(cnt);
+            if (check_merge && x >= xrec_lo && __builtin_amdgcn_readlane(yireg, x & 63) == y) { merged = true; break; }
+            const int a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+            const int Bx = min(B, W - a);
+            if (y < a) { e = 1; break; }
+            int yc = min(y, a + Bx - 1);                     // past the band: implicit left moves
+            const int g = x >> 4, sh = 15 - (x & 15);
+            int found = -1, cbit = 0;
+            for (;;) {
+                if (g != gcur || yc < yb || yc > yb + 255) {
+                    // the window of the group above was fetched ahead for this group as well, a little to the left: take it
+                    // if the column still lies in its right part (room for the steps to the left that are to come)
+                    if (gpre == g && yc >= ybpre + 96 && yc <= ybpre + 255) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) win[q] = pre[q];
+                        yb = ybpre;
+                    } else {
+                        const int want = max(lo, yc - 191);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) win[q] = dirs[(size_t)g * RS + (want + 64 * q + lane - lo) % RS];
+                        yb = want;
+                    }
+                    gcur = g;
+                    if (g > (x_lo >> 4)) {
+                        gpre = g - 1; ybpre = max(lo, yb - 56);      // a trace drifts left by about 4.5 columns per row
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) pre[q] = dirs[(size_t)(g - 1) * RS + (ybpre + 64 * q + lane - lo) % RS];
+                    }
+                }
+                {
+                    const int q0 = (yc - yb) >> 6;
+                    const uint32_t wq = q0 == 0 ? win[0] : q0 == 1 ? win[1] : q0 == 2 ? win[2] : win[3];
+                    const int cy = yb + 64 * q0 + lane;
+                    const unsigned long long mk = __ballot(cy <= yc && cy >= a && !((wq >> sh) & 1u));
+                    if (mk) {
+                        const int t = 63 - __builtin_clzll(mk);
+                        found = yb + 64 * q0 + t;
+                        const unsigned long long ck = __ballot((wq >> (16 + sh)) & 1u);
+                        cbit = (int)((ck >> t) & 1ull);
+                    } else {
+#pragma unroll
+                        for (int q = 2; q >= 0; --q) {
+                            if (found < 0 && q < q0) {
+                                const int cy2 = yb + 64 * q + lane;
+                                const unsigned long long mk2 = __ballot(cy2 >= a && !((win[q] >> sh) & 1u));
+                                if (mk2) {
+                                    const int t = 63 - __builtin_clzll(mk2);
+                                    found = yb + 64 * q + t;
+                                    const unsigned long long ck = __ballot((win[q] >> (16 + sh)) & 1u);
+                                    cbit = (int)((ck >> t) & 1ull);
+                                }
+                            }
+                        }
+                    }
+                }
+                if (found >= 0) break;
+                if (yb <= a) { e = 2; break; }
+                yc = yb - 1;
+            }
+            if (e) break;
+            const int yy = found;
+            const int nv = cbit ? (yy << 1) : ((yy << 1) | 1);                       // PW:1394 (c) / PW:1404 (d)
+            if (x >= xrec_lo) cnt -= __builtin_amdgcn_readlane(ncreg, x & 63) & 1;   // replaces a recorded step
+            cnt += nv & 1;
+            ncreg = (lane == (x & 63)) ? nv : ncreg;
+            yireg = (lane == (x & 63)) ? y : yireg;
+            y = cbit ? yy - 1 : yy;
+            --x;
+            if (x >= 0 && y < 0) { e = 3; break; }
+        }
+        // rows above x are recorded now (a pass that broke off leaves the rows below as they were)
+        if (!merged) xrec_lo = e ? min(xrec_lo, x + 1) : x_lo;
+        if (!e && !merged) yexit = y;
+        return e;
+    };
+#define TB_POST(FLAG, ARR) if (lane == 0) __hip_atomic_store(&hand[c], TB_WORD(ttag, FLAG, cnt, ARR, broke ? TB_BROKE : (unsigned)(yexit + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    bool merged = false;
+#ifdef PWR_DIAG
+    const unsigned long long tb_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tb_t1 = tb_t0;
+    int tb_looks = 0, tb_retr = 0;
+#endif
+    if (top) {
+        // entry: minimum of the last row over y in [ylow, W-1], ties -> largest y; columns past the band carry the value of
+        // the last band cell (PW:287)
+        const int wx = UNI(way[L - 1]);
+        const int a = max(0, wx - H), Bx = min(B, W - a);
+        int ylow = max(-1, wx - H) + 1;
+        if (ylow > W - 1) ylow = W - 1;
+        unsigned long long key = ~0ull;
+        for (int yy = max(ylow, a) + lane; yy < a + Bx; yy += 64) {
+            const unsigned v = lastM[(yy - lo) % RS];
+            const unsigned long long k2 = ((unsigned long long)v << 32) | (unsigned)(~(unsigned)yy);
+            key = k2 < key ? k2 : key;
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other < key ? other : key;
+        }
+        const unsigned vmin = (unsigned)(key >> 32);
+        int entry = (key == ~0ull) ? -1 : (int)(~(unsigned)key);
+        if (a + B <= W - 1) {
+            const unsigned lastval = lastM[(a + B - 1 - lo) % RS];
+            if (entry < 0 || lastval <= vmin) entry = W - 1;
+        }
+        entry = UNI(entry);
+        if (lane == 0) m->entry = entry;
+        err = entry < 0 ? 4 : pass(entry, false, merged);
+    } else {
+        int arr = UNI(way[x_top + 1]) - 1;                         // the guess
+        broke = pass(arr, false, merged) != 0;                     // (a guess that breaks off is harmless: the rows above the break are recorded)
+        TB_POST(1, arr)
+#ifdef PWR_DIAG
+        tb_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
+        for (int look = 0; look < (1 << 16) && !err; ++look) {
+#ifdef PWR_DIAG
+            tb_looks += 1;
+#endif
+            int t = c + 1;                                     // chunks [c + 1, t) are consistent so far
+            int verdict = 0;                                   // 1: the chain above closes at a final chunk, 2: chunk `bad` is not settled
+            int bad = -1;
+            unsigned long long wbad = 0;
+            unsigned ex_first = 0;                             // exit field of chunk c + 1
+            while (!verdict && !err) {
+                // words of the chunks t .. t + 63, and of t + 64 for the last lane's comparison
+                const int j = min(t + lane, nch - 1);
+                unsigned long long w = 0, wn = 0;
+                int st_j = 0;
+                for (int spin = 0; spin < TR_SPIN_LIMIT; ++spin) {
+                    w = __hip_atomic_load(&hand[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    st_j = ((unsigned)(w >> 50) == ttag) ? (int)((w >> 48) & 3ull) : 0;
+                    if (__ballot(st_j == 0) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (__ballot(st_j == 0) != 0ull || __ballot(st_j == 3) != 0ull) { err = 5; break; }
+                const unsigned ex_j = (unsigned)w & 0x1fffffu, ar_j = (unsigned)(w >> 21) & 0xfffffu;
+                unsigned ex_up = (unsigned)__shfl_down((int)ex_j, 1);               // exit of the chunk above chunk j
+                if (lane == 63) {
+                    const int j2 = min(t + 64, nch - 1);
+                    int s2 = 0;
+                    for (int spin = 0; spin < TR_SPIN_LIMIT; ++spin) {
+                        wn = __hip_atomic_load(&hand[j2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s2 = ((unsigned)(wn >> 50) == ttag) ? (int)((wn >> 48) & 3ull) : 0;
+                        if (s2) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    ex_up = s2 == 0 || s2 == 3 ? 0u : ((unsigned)wn & 0x1fffffu);
+                }
+                const bool valid = t + lane <= nch - 1;
+                const bool fin = valid && st_j == 2;
+                const bool cons = valid && (st_j == 2 || (t + lane < nch - 1 && ar_j == ex_up));   // (arrival + 1 == exit + 1)
+                if (t == c + 1) ex_first = (unsigned)__builtin_amdgcn_readlane((int)ex_j, 0);
+                const unsigned long long mfin = __ballot(fin), mbad = __ballot(valid && !cons);
+                const int ffin = mfin ? __builtin_ctzll(mfin) : 64, fbad = mbad ? __builtin_ctzll(mbad) : 64;
+                if (ffin < 64 && ffin <= fbad) verdict = 1;
+                else if (fbad < 64) {
+                    verdict = 2; bad = t + fbad;
+                    wbad = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(w >> 32), fbad) << 32) | (unsigned)__builtin_amdgcn_readlane((int)w, fbad);
+                }
+                else t += 64;                                  // 64 more consistent chunks: look further up
+            }
+            if (err) break;
+            if (ex_first == TB_BROKE) {
+                // the record of the chunk above breaks off: if that is its true record, the trace itself is inconsistent
+                if (verdict == 1) { err = 6; break; }
+            } else if ((int)ex_first - 1 != arr) {
+                // the chunk above leaves in another column than this one started from: trace again from there, at once (its
+                // exit is usually what it will stay; if not, this happens again)
+                arr = (int)ex_first - 1;
+#ifdef PWR_DIAG
+                tb_retr += 1;
+#endif
+                const int e1 = pass(arr, true, merged);
+                if (e1) broke = true;
+                else if (merged) { if (xrec_lo > x_lo) broke = true; }    // merged into a record that breaks off further down
+                else broke = false;
+                TB_POST(1, arr)
+                continue;
+            } else if (verdict == 1) break;                    // traced from the true arrival: final
+            // something above is not settled yet: look again when that chunk has posted anew
+            for (int spin = 0; spin < TR_SPIN_LIMIT; ++spin) {
+                const unsigned long long w = __hip_atomic_load(&hand[bad], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (UNI((unsigned)w) != (unsigned)wbad || UNI((unsigned)(w >> 32)) != (unsigned)(wbad >> 32)) break;
+                if (spin == TR_SPIN_LIMIT - 1) { err = 5; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (!err && broke) err = 6;                               // the true trace breaks off in this chunk
+        if (!err) { TB_POST(2, arr) }
+    }
+    if (x_lo + lane < L) { newcol[x_lo + lane] = ncreg; yin[x_lo + lane] = yireg; }
+    if (top || err) {
+        if (lane == 0)
+            __hip_atomic_store(&hand[c], TB_WORD(ttag, err ? 3 : 2, cnt, 0, (unsigned)(yexit + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#ifdef PWR_DIAG
+    if (job == 0 && lane == 0) {
+        const unsigned long long n_ = __builtin_amdgcn_s_memrealtime();
+        if (tb_retr) atomicAdd(&st.hdr->dbg[24], (unsigned long long)tb_retr);   // retraces
+        if (c == 0 || top) {
+            unsigned long long *d_ = st.hdr->dbg + (top ? 20 : 16);
+            d_[0] += (top ? n_ : tb_t1) - tb_t0; d_[1] += n_ - (top ? n_ : tb_t1); d_[3] += 1;
+            if (c == 0) { st.hdr->dbg[25] += (unsigned long long)tb_looks; st.hdr->dbg[26] += (unsigned long long)nch; }
+        }
+    }
+#endif
+    if (err) {
+        if (lane == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+        return;
+    }
+    if (c == 0) {
+        // every chunk above is final, or its latest word is of a record traced from the true arrival: their 'up' moves add up
+        // to the columns this realignment opens
+        int tot = 0;
+        for (int j = lane; j < nch; j += 64)
+            tot += (int)((__hip_atomic_load(&hand[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 41) & 0x7full);
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        if (lane == 0) m->nnew = tot;
+    }
+#undef TB_POST
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2878,7 +3163,7 @@ struct pwr_ctx {
     int force64 = 0;                      // test hook: every job takes k_fill64
     int evcap = EVCAP;                    // test hook: event-list renumbering up to this many structural events per commit
     int stall_test = 0;                   // test hook: this many k_fill_v3 launches have their first job stall
-    int par_trace = 1;                    // 1: speculative-parallel traceback (k_trace_par), 0: single-wave k_trace_wp
+    int par_trace = 2;                    // 2: one wave per 64 rows, hand-over without a chain (k_trace_blk); 1: 64 chunks handing over top-down (k_trace_par); 0: single-wave k_trace_wp
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int spec_len = 6;                     // percent a speculative row may be longer than the first row of its batch (option "spec_len")
     int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP; cross-check and fallback)
@@ -3076,10 +3361,11 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
             hipStreamSynchronize(c->stream) != hipSuccess) return PWR_ERR_DEVICE;
         c->fill_epoch = 0;
     }
-    if ((rc = dmalloc(c, &jb.gtr, (size_t)njobs * TRK))) return rc;
+    jb.trk = std::max(TRK, jb.Lmax / 64 + 1);
+    if ((rc = dmalloc(c, &jb.gtr, (size_t)njobs * jb.trk))) return rc;
     if ((rc = dmalloc(c, &jb.diag, (size_t)njobs * 32 * 4096))) return rc;
     if (hipMemsetAsync(jb.diag, 0, (size_t)njobs * 32 * 4096 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
-    if (hipMemsetAsync(jb.gtr, 0, (size_t)njobs * TRK * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
+    if (hipMemsetAsync(jb.gtr, 0, (size_t)njobs * jb.trk * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     c->trace_epoch = 0;
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
     if (hipMemset(jb.meta, 0, sizeof(JobMeta) * njobs) != hipSuccess) return PWR_ERR_DEVICE;
@@ -3394,9 +3680,10 @@ static int enqueue_batch(pwr_ctx *c)
     if ((rc = launch_fill(c, n))) return rc;
     hipLaunchKernelGGL(k_fill64, dim3(n), dim3(F64_NT), 0, c->stream, c->st, c->jb);       // jobs the gather flagged wide (none, normally)
     if (c->par_trace) {
-        if (++c->trace_epoch >= (1u << 22)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * TRK * 8, c->stream)); c->trace_epoch = 1; }
+        if (++c->trace_epoch >= (1u << 14)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * c->jb.trk * 8, c->stream)); c->trace_epoch = 1; }
         c->jb.trace_tag = c->trace_epoch;
-        hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
+        if (c->par_trace == 2 && c->st.colcap < TB_MAXCOL) hipLaunchKernelGGL(k_trace_blk, dim3(n, (c->jb.Lmax / 64 + TB_W) / TB_W), dim3(TB_W * 64), 0, c->stream, c->st, c->jb);
+        else hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
     }
     else hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
     hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n, c->d_rowids);
@@ -3593,11 +3880,11 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "stall_test")) { if (value < 0 || value > 1000000) return PWR_ERR_ARG; c->stall_test = (int)value; return PWR_OK; }
     if (!strcmp(key, "evcap")) { if (value < 0 || value > EVCAP) return PWR_ERR_ARG; c->evcap = (int)value; c->jb.evcap = (int)value; return PWR_OK; }
     if (!strcmp(key, "force64")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->force64 = (int)value; c->jb.force64 = (int)value; return PWR_OK; }
-    if (!strcmp(key, "ptrace")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
+    if (!strcmp(key, "ptrace")) { if (value < 0 || value > 2) return PWR_ERR_ARG; c->par_trace = (int)value; return PWR_OK; }
     if (!strcmp(key, "slack")) { if (c->on_device || value < 0) return PWR_ERR_ARG; c->cap_slack = (int)value; return PWR_OK; }
     // (test hooks: where the launch counters behind the mailbox / hand-over tags stand, so that their wrap-around can be exercised)
     if (!strcmp(key, "fill_epoch")) { if (value < 0 || value >= (1 << 15)) return PWR_ERR_ARG; c->fill_epoch = (unsigned)value; return PWR_OK; }
-    if (!strcmp(key, "trace_epoch")) { if (value < 0 || value >= (1 << 22)) return PWR_ERR_ARG; c->trace_epoch = (unsigned)value; return PWR_OK; }
+    if (!strcmp(key, "trace_epoch")) { if (value < 0 || value >= (1 << 14)) return PWR_ERR_ARG; c->trace_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "seg_rows")) { if (c->on_device || value < 0 || value > 1000000) return PWR_ERR_ARG; c->seg_rows = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_pct")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->warm_pct = (int)value; return PWR_OK; }

@@ -29,4 +29,5 @@ print(f"  commit_job x {nc}: marks {d[1]/nc/100:.1f}  newcols {d[2]/nc/100:.1f} 
 for nm, o in (("bottom chunk", 16), ("top chunk", 20)):
     k = max(1, d[o + 3])
     print(f"trace {nm}: phase0 {d[o]/k/100:.1f} us, waiting for the chunk above {d[o+1]/k/100:.1f} us, phase1 {d[o+2]/k/100:.1f} us  (job 0 of {k} launches)")
+print(f"k_trace_blk job 0: chunks per trace {d[26]/max(1,d[19]):.0f}, chunks that retraced {d[24]/max(1,d[19]):.1f}, looks of the bottom chunk {d[25]/max(1,d[19]):.1f}")
 g.close()

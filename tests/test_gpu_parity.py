@@ -253,7 +253,7 @@ def test_launch_tag_wraparound(oracle):
     g.trim_ends()
     g.total_score()                                  # first device call: allocates, counters at 0
     g.set_option("fill_epoch", (1 << 15) - 5)
-    g.set_option("trace_epoch", (1 << 22) - 7)
+    g.set_option("trace_epoch", (1 << 14) - 7)
     h = oracle.create(rows, bw)
     oracle.lib.pwo_trim(h)
     for _ in range(2):
