@@ -400,26 +400,34 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
         s_xb[tid] = xb;
     }
     __syncthreads();
-    for (int s2 = 0; s2 < S; ++s2) {
-        unsigned long long cs = 0;
-        for (int x = s_xb[s2] + tid; x < s_x[s2 + 1]; x += GATHER_NT) cs += (unsigned long long)min(B, W - max(0, way[x] - H));
-        for (int o = 32; o > 0; o >>= 1) cs += __shfl_xor(cs, o);
-        if ((tid & 63) == 0 && cs) atomicAdd(&s_cells[s2], cs);
+    // cells of the rows [xb, xe): B each, less what the MSA's right edge cuts off the band (PW:1497) -- only the rows from
+    // the first one whose band reaches it, a suffix of the row (Way[] is increasing)
+    __shared__ int s_xr, s_grow[SEG_MAX + 1];
+    if (tid == 0) {
+        int a = 0, b = L;                                     // first row x with max(0, way[x] - H) + B > W
+        while (a < b) { const int mid = (a + b) >> 1; if (max(0, way[mid] - H) + B > W) b = mid; else a = mid + 1; }
+        s_xr = a;
+        int grow = 0;
+        for (int s2 = 0; s2 <= S; ++s2) { s_grow[s2] = grow; if (s2 < S) grow += s_x[s2 + 1] - s_xb[s2]; }
     }
     __syncthreads();
-    if (tid == 0) {
-        int grow = 0;
-        for (int s2 = 0; s2 < SEG_MAX; ++s2) {
-            SegDesc d;
-            d.job = job; d.s = s2; d.active = s2 < S ? 1 : 0;
-            d.xb = d.xown = d.xe = 0; d.fin = 0; d.grow0 = 0; d.cells = 0;
-            if (s2 < S) {
-                d.xb = s_xb[s2]; d.xown = s_x[s2]; d.xe = s_x[s2 + 1]; d.fin = s2 == S - 1 ? 1 : 0;
-                d.grow0 = grow; d.cells = s_cells[s2];
-                grow += d.xe - d.xb;
-            }
-            sg[s2] = d;
+    const int xr = s_xr;
+    for (int x = xr + tid; x < L; x += GATHER_NT) {
+        const unsigned long long cut = (unsigned long long)(B - min(B, W - max(0, way[x] - H)));
+        if (cut) for (int s2 = S - 1; s2 >= 0 && s_x[s2 + 1] > x; --s2) if (s_xb[s2] <= x) atomicAdd(&s_cells[s2], cut);
+    }
+    __syncthreads();
+    if (tid < SEG_MAX) {
+        const int s2 = tid;
+        SegDesc d;
+        d.job = job; d.s = s2; d.active = s2 < S ? 1 : 0;
+        d.xb = d.xown = d.xe = 0; d.fin = 0; d.grow0 = 0; d.cells = 0;
+        if (s2 < S) {
+            d.xb = s_xb[s2]; d.xown = s_x[s2]; d.xe = s_x[s2 + 1]; d.fin = s2 == S - 1 ? 1 : 0;
+            d.grow0 = s_grow[s2];
+            d.cells = (unsigned long long)(d.xe - d.xb) * (unsigned long long)B - s_cells[s2];
         }
+        sg[s2] = d;
     }
 }
 
@@ -2692,8 +2700,12 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     const int take = min(nnew, nfree);
     const unsigned newver = (unsigned)h->version + 1u;
     PH_T0()
-    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[3] = 0; s_i[4] = 0x7fffffff; s_i[5] = 0; }   // [0] freed slots, [1] some column lost its last base, [3] any change, [4] first ordinal that changes, [5] structural events
-    for (int y = ny0 + tid; y <= nyL; y += COMMIT_NT) mark2[y - lo] = 0;
+    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[3] = 0; s_i[4] = 0x7fffffff; s_i[5] = 0; s_i[8] = 0; }   // [8] changed columns, [0] freed slots, [1] some column lost its last base, [3] any change, [4] first ordinal that changes, [5] structural events
+    {
+        // (whole 8-byte units: the bytes around the new extent belong to nobody else, symbols outside it are decided by the extent)
+        unsigned long long *m8 = reinterpret_cast<unsigned long long *>(mark2);
+        for (int u = ((ny0 - lo) >> 3) + tid; u <= ((nyL - lo) >> 3); u += COMMIT_NT) m8[u] = 0ull;
+    }
     __syncthreads();
     for (int x = tid; x < L; x += COMMIT_NT) {
         const int c = newcol[x];
@@ -2746,10 +2758,31 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     // 2. Columns_Downdater + Column_Updater fused (PW:1172-1243): only columns whose symbol for this
     //    row really changes are touched (and stamped with the new version)
     const int u0 = min(way0, ny0), u1 = max(wayL, nyL);
-    for (int y = u0 + tid; y <= u1; y += COMMIT_NT) {
-        const int so = row_symbol(mark, y, lo, way0, wayL);
-        const int sn = row_symbol(mark2, y, lo, ny0, nyL);
-        if (so != sn) {
+    // (a) find them, eight columns at a time: a unit that lies inside both extents and holds the same marks before and after
+    //     has none; (b) one thread per changed column
+    {
+        const unsigned long long *mo8 = reinterpret_cast<const unsigned long long *>(mark), *mn8 = reinterpret_cast<const unsigned long long *>(mark2);
+        const int ui0 = max(way0, ny0), ui1 = min(wayL, nyL);                      // columns inside both extents
+        int *list = st.newidx;                                                     // (scratch until the renumbering)
+        for (int u = ((u0 - lo) >> 3) + tid; u <= ((u1 - lo) >> 3); u += COMMIT_NT) {
+            const int yb8 = lo + 8 * u;
+            const unsigned long long wo = mo8[u], wn = mn8[u];
+            if (yb8 >= ui0 && yb8 + 7 <= ui1 && wo == wn) continue;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int y = yb8 + b;
+                if (y < u0 || y > u1) continue;
+                const int vo = (int)((wo >> (8 * b)) & 0xffull), vn = (int)((wn >> (8 * b)) & 0xffull);
+                const int so = (y < way0 || y > wayL) ? 5 : (vo == 7 ? 5 : (vo ? vo - 1 : 4));     // row_symbol()
+                const int sn = (y < ny0 || y > nyL) ? 5 : (vn == 7 ? 5 : (vn ? vn - 1 : 4));
+                if (so != sn) list[atomicAdd(&s_i[8], 1)] = y | (so << 24) | (sn << 28);
+            }
+        }
+        __syncthreads();
+        const int nchg = s_i[8];
+        for (int i = tid; i < nchg; i += COMMIT_NT) {
+            const int e_ = list[i];
+            const int y = e_ & 0xffffff, so = (e_ >> 24) & 15, sn = (e_ >> 28) & 15;
             const int slot = order[y];
             Tally *t = &st.tally[slot];
             uint32_t w4 = 0;
@@ -2820,16 +2853,45 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         // freed slots (read before anything moves) and the scratch copy of what moves
         for (int e = tid; e < nev; e += COMMIT_NT)
             if (!(ev->skey[e] & 1)) { const int p = atomicAdd(&s_i[0], 1); st.freelist[nfree - take + p] = order[ev->skey[e] >> 1]; }
-        auto seg_of = [&](int i) { int a = 0, b = ns - 1; while (a < b) { const int mid = (a + b + 1) >> 1; if (ev->seg_pre[mid] <= i) a = mid; else b = mid - 1; } return a; };
-        for (int i = tid; i < total; i += COMMIT_NT) { const int sgi = seg_of(i); tmp[i] = order[ev->seg_lo[sgi] + (i - ev->seg_pre[sgi])]; }
-        __threadfence_block();
-        __syncthreads();
         int *ordw = const_cast<int *>(order);
-        for (int i = tid; i < total; i += COMMIT_NT) {
-            const int sgi = seg_of(i);
-            const int yn = ev->seg_lo[sgi] + (i - ev->seg_pre[sgi]) + ev->seg_sh[sgi];
-            const int slot = tmp[i];
-            ordw[yn] = slot; st.rank[slot] = yn;
+        if (ns <= 24) {
+            // a few long stretches (one column more or less shifts everything behind it): plain copy loops, four entries in flight
+            for (int sgi = 0; sgi < ns; ++sgi) {
+                const int *src = order + ev->seg_lo[sgi];
+                int *dst = tmp + ev->seg_pre[sgi];
+                const int n_ = ev->seg_pre[sgi + 1] - ev->seg_pre[sgi];
+                int i = tid;
+                for (; i + 3 * COMMIT_NT < n_; i += 4 * COMMIT_NT) {
+                    const int v0 = src[i], v1 = src[i + COMMIT_NT], v2 = src[i + 2 * COMMIT_NT], v3 = src[i + 3 * COMMIT_NT];
+                    dst[i] = v0; dst[i + COMMIT_NT] = v1; dst[i + 2 * COMMIT_NT] = v2; dst[i + 3 * COMMIT_NT] = v3;
+                }
+                for (; i < n_; i += COMMIT_NT) dst[i] = src[i];
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (int sgi = 0; sgi < ns; ++sgi) {
+                const int *src = tmp + ev->seg_pre[sgi];
+                const int y0_ = ev->seg_lo[sgi] + ev->seg_sh[sgi];
+                const int n_ = ev->seg_pre[sgi + 1] - ev->seg_pre[sgi];
+                int i = tid;
+                for (; i + 3 * COMMIT_NT < n_; i += 4 * COMMIT_NT) {
+                    const int v0 = src[i], v1 = src[i + COMMIT_NT], v2 = src[i + 2 * COMMIT_NT], v3 = src[i + 3 * COMMIT_NT];
+                    ordw[y0_ + i] = v0; ordw[y0_ + i + COMMIT_NT] = v1; ordw[y0_ + i + 2 * COMMIT_NT] = v2; ordw[y0_ + i + 3 * COMMIT_NT] = v3;
+                    st.rank[v0] = y0_ + i; st.rank[v1] = y0_ + i + COMMIT_NT; st.rank[v2] = y0_ + i + 2 * COMMIT_NT; st.rank[v3] = y0_ + i + 3 * COMMIT_NT;
+                }
+                for (; i < n_; i += COMMIT_NT) { const int v = src[i]; ordw[y0_ + i] = v; st.rank[v] = y0_ + i; }
+            }
+        } else {
+            auto seg_of = [&](int i) { int a = 0, b = ns - 1; while (a < b) { const int mid = (a + b + 1) >> 1; if (ev->seg_pre[mid] <= i) a = mid; else b = mid - 1; } return a; };
+            for (int i = tid; i < total; i += COMMIT_NT) { const int sgi = seg_of(i); tmp[i] = order[ev->seg_lo[sgi] + (i - ev->seg_pre[sgi])]; }
+            __threadfence_block();
+            __syncthreads();
+            for (int i = tid; i < total; i += COMMIT_NT) {
+                const int sgi = seg_of(i);
+                const int yn = ev->seg_lo[sgi] + (i - ev->seg_pre[sgi]) + ev->seg_sh[sgi];
+                const int slot = tmp[i];
+                ordw[yn] = slot; st.rank[slot] = yn;
+            }
         }
         // the new columns: after old ordinal y, before any column opened there by a later base of this row (PW:1245-1332)
         for (int x = tid; x < L; x += COMMIT_NT) {
@@ -2967,7 +3029,7 @@ __device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsig
 __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs jb, int njobs, const int *rowids)
 {
     __shared__ unsigned sh[COMMIT_NT / 64];
-    __shared__ int s_i[8];
+    __shared__ int s_i[12];
     __shared__ CommitEv evs;
     Hdr *h = st.hdr;
 #ifdef PWR_DIAG
@@ -3452,7 +3514,7 @@ static int upload(pwr_ctx *c)
     DState &st = c->st;
     st = DState{};
     st.T = T; st.B = c->B; st.H = c->H; st.Lmax = c->Lmax;
-    st.colcap = c->cap_slack ? 2 * W + 2 * c->Lmax + c->cap_slack : W + c->Lmax + 128;
+    st.colcap = ((c->cap_slack ? 2 * W + 2 * c->Lmax + c->cap_slack : W + c->Lmax + 128) + 15) & ~15;   // (a multiple of 16: the per-job mark arrays are read 8 bytes at a time)
     st.slotcap = st.colcap;
     int rc;
     Hdr hdr{};
@@ -3547,7 +3609,7 @@ static int grow_state(pwr_ctx *c, long long growth)
     if (rc) return rc;
     if (h.status) return h.status;
     DState &st = c->st;
-    const size_t ncap = (size_t)std::max<long long>(2LL * st.colcap, (long long)std::max(h.W, h.nslots) + 2 * growth + 8192);
+    const size_t ncap = ((size_t)std::max<long long>(2LL * st.colcap, (long long)std::max(h.W, h.nslots) + 2 * growth + 8192) + 15) & ~(size_t)15;
     const size_t ocol = st.colcap, oslot = st.slotcap;
     if ((rc = regrow(c, &st.tally, oslot, ncap))) return rc;
     if ((rc = regrow(c, &st.order0, ocol, ncap))) return rc;
