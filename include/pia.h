@@ -25,7 +25,9 @@ extern "C" {
 
 typedef struct pia_ctx pia_ctx;
 
-/* The template (lower-case acgt, what ReadingTemplate IA:214-262 leaves) is uploaded once. */
+/* The template (acgt in either case, what ReadingTemplate IA:214-262 leaves) is uploaded once.  Any other byte -- here and in
+ * the reads of pia_align -- is refused with PWR_ERR_INPUT (the reference's reader reduces its input to the four bases before
+ * it compares anything, IA:190-209; the kernels would silently take another byte for one of them). */
 int pia_create(pia_ctx **out, const char *templ, int templ_len, int device);
 void pia_destroy(pia_ctx *ctx);
 
@@ -35,8 +37,10 @@ void pia_destroy(pia_ctx *ctx);
 int pia_align(pia_ctx *ctx, int nreads, const char *bases, const long long *off, int *align, int *dist);
 /* DP cells filled so far (read length x template length per read) and the summed duration of the fill kernel in ms. */
 int pia_get_stats(pia_ctx *ctx, unsigned long long *cells, double *fill_ms);
-/* "mem_budget": bytes of device memory for the stored direction bits of one batch of reads (0 = the default, 22 GB; up to
- * four such buffers are in flight); a read whose band alone is larger still gets a batch of its own. */
+/* "mem_budget": bytes of device memory for the stored direction bits of one batch of reads (0 = the default: 22 GB, or
+ * less when the card has less to spare -- three quarters of the free memory over the four buffers in flight; an allocation
+ * that fails all the same halves it and the batches are planned again); a read whose band alone is larger still gets a
+ * batch of its own. */
 int pia_set_option(pia_ctx *ctx, const char *key, long long value);
 /* Where the last pia_align spent its time, ms: [0] all of it, [1] set-up and upload, [2] pass 1, [3] pass 2 with the
  * tracebacks, [4] the number of batches pass 2 took (not a time), [5] download. */

@@ -220,10 +220,18 @@ struct pia_ctx {
         }                                                                              \
     } while (0)
 
+// the kernels take a base's code from two bits of its character ((c >> 1) & 3: a c g t, either case): anything else would
+// silently alias one of the four, so it is refused at the boundary
+static inline bool ia_is_base(char ch)
+{
+    switch (ch) { case 'a': case 'c': case 'g': case 't': case 'A': case 'C': case 'G': case 'T': return true; default: return false; }
+}
+
 extern "C" int pia_create(pia_ctx **out, const char *templ, int templ_len, int device)
 {
     if (!out || !templ || templ_len < 0) return PWR_ERR_ARG;
     if (templ_len > PIA_MAX_LINE) return PWR_ERR_RANGE;                              // IA:214 Template[70000]
+    for (int y = 0; y < templ_len; ++y) if (!ia_is_base(templ[y])) return PWR_ERR_INPUT;     // (the reference's reader leaves nothing else, IA:190-209)
     pia_ctx *c = new (std::nothrow) pia_ctx();
     if (!c) return PWR_ERR_NOMEM;
     c->device = device; c->L2 = templ_len;
@@ -325,6 +333,7 @@ extern "C" int pia_align(pia_ctx *c, int nreads, const char *bases, const long l
     const double t_start = now_ms();
     for (double &t : c->t_ms) t = 0;
     const long long b0 = off[0], nb = off[nreads] - off[0];
+    for (long long i = 0; i < nb; ++i) if (!ia_is_base(bases[b0 + i])) return PWR_ERR_INPUT;
     std::vector<IaRead> hr(nreads);
     std::vector<int> order(nreads);
     for (int j = 0; j < nreads; ++j) {
@@ -359,11 +368,20 @@ extern "C" int pia_align(pia_ctx *c, int nreads, const char *bases, const long l
     if (hipEventElapsedTime(&ms, d.e0, d.e1) == hipSuccess) { c->fill_ms += ms; c->t_ms[2] = ms; }
     // pass 2 in batches whose bands fit the budget, IA_NBUF of them in flight, each with its buffer and stream: the tail of
     // one batch (its longest reads) runs beside the bulk of the next ones
-    const size_t budget = c->mem_budget ? c->mem_budget : (size_t)22 << 30;
+    // The budget per buffer: 22 GB by default, but never more than the card has to spare right now (other contexts or ranks
+    // may share it); if an allocation fails all the same, the batches are planned again with half of it.
+    size_t budget = c->mem_budget ? c->mem_budget : (size_t)22 << 30;
+    if (!c->mem_budget) {
+        size_t free_b = 0, total_b = 0, have = 0;
+        for (size_t cap : c->codes_cap) have += cap * sizeof(uint2);                 // (what this context holds already counts as available)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, std::max<size_t>((free_b + have) / 4 * 3 / IA_NBUF, (size_t)64 << 20));
+    }
     const size_t WPS = (size_t)((c->WPL + 1) & ~1);
     size_t maxwords = 0;
     std::vector<int> bend;                                                            // batch ends in `order`
-    {
+    for (;;) {
+        maxwords = 0;
+        bend.clear();
         size_t words = 0;
         for (int k = 0; k < nreads; ++k) {
             IaRead &r = hr[order[k]];
@@ -375,13 +393,17 @@ extern "C" int pia_align(pia_ctx *c, int nreads, const char *bases, const long l
         }
         bend.push_back(nreads);
         maxwords = std::max(maxwords, words);
+        bool ok = true;
+        for (size_t b = 0; b < std::min<size_t>(bend.size(), IA_NBUF) && ok; ++b)
+            if (c->codes_cap[b] < maxwords) {                                         // kept for the next call: large allocations are slow
+                (void)hipFree(c->codes[b]); c->codes[b] = nullptr; c->codes_cap[b] = 0;
+                if (hipMalloc(&c->codes[b], std::max<size_t>(maxwords, 1) * sizeof(uint2)) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+                else c->codes_cap[b] = maxwords;
+            }
+        if (ok) break;
+        if (bend.size() == (size_t)nreads || budget <= ((size_t)16 << 20)) return PWR_ERR_NOMEM;   // one read per batch already, or nothing left to halve
+        budget /= 2;
     }
-    for (size_t b = 0; b < std::min<size_t>(bend.size(), IA_NBUF); ++b)
-        if (c->codes_cap[b] < maxwords) {                                             // kept for the next call: large allocations are slow
-            (void)hipFree(c->codes[b]); c->codes[b] = nullptr; c->codes_cap[b] = 0;
-            if (hipMalloc(&c->codes[b], std::max<size_t>(maxwords, 1) * sizeof(uint2)) != hipSuccess) return PWR_ERR_NOMEM;
-            c->codes_cap[b] = maxwords;
-        }
     HIPC(hipMemcpyAsync(d.reads, hr.data(), sizeof(IaRead) * nreads, hipMemcpyHostToDevice, c->stream));
     HIPC(hipStreamSynchronize(c->stream));
     const double t_p2 = now_ms();

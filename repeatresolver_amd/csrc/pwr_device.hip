@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)   //
 #define V4_RB 128                                    // ring slots (rows); the fetcher looks at most 64 rows ahead
 
 #ifdef PWR_DIAG
-#define DG_DECL unsigned long long dg_wait_fast = 0, dg_wait_gen = 0, dg_wait_setup = 0, dg_t = 0, dg_t2 = 0, dg_cyc_int = 0, dg_cyc_gen16 = 0, dg_ts1 = 0, dg_ts2 = 0; unsigned dg_log = 0; unsigned dg_int = 0, dg_gen16 = 0, dg_general = 0, dg_nowork = 0, dg_runs = 0, dg_switch = 0;
+#define DG_DECL unsigned long long dg_wait_fast = 0, dg_wait_gen = 0, dg_wait_setup = 0, dg_t = 0, dg_t2 = 0, dg_cyc_int = 0, dg_cyc_gen16 = 0, dg_ts1 = 0, dg_ts2 = 0, dg_tl2 = 0; unsigned dg_log = 0; unsigned dg_int = 0, dg_gen16 = 0, dg_general = 0, dg_nowork = 0, dg_runs = 0, dg_switch = 0;
 #define DG_T0() dg_t = __builtin_amdgcn_s_memtime();
 #define DG_ADD(ACC) ACC += __builtin_amdgcn_s_memtime() - dg_t;
 #define DG_INC(CNT, N) CNT += (N);
@@ -1083,17 +1083,25 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)   //
 #define DG_ADD(ACC)
 #define DG_INC(CNT, N)
 #endif
-template <int NW, int C>
-__global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
+template <int NW, int C, bool WG1>
+__global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobBufs jb)
 {
     constexpr int MS = 64 * C, RS = NW * MS;
-    __shared__ __attribute__((aligned(16))) int ldsS1[2][4][MS];
-    __shared__ unsigned long long rP[V4_RB], rM[V4_RB];                  // the neighbour's {P_end, tag}, {M_last, tag}
-    __shared__ int wprog, wdone;                                         // worker's progress (rows), worker finished
+    // WG1: the NW waves of a segment are ONE work-group (no fetchers): a wave stores the words it publishes straight into its
+    // right neighbour's ring in LDS (and the running minimum also to global memory, where the rare readers of a row's total
+    // minimum find it).  A hand-over is then an LDS round trip instead of an L2 one plus the fetcher's poll; a ring slot is
+    // written again only when the reader is past it (its progress counter), so no wave runs more than RB rows ahead of its
+    // reader.  On its own CU a segment has every SIMD to two of its waves (NW = 8).
+    constexpr int NL = WG1 ? NW : 1;                                      // waves whose tables and rings live in this work-group's LDS
+    constexpr int RB = WG1 ? 64 : V4_RB;                                  // ring slots (rows)
+    __shared__ __attribute__((aligned(16))) int ldsS1[NL][2][4][MS];
+    __shared__ unsigned long long rP[NL][RB], rM[NL][RB];                // the left neighbour's {P_end, tag}, {M_last, tag}
+    __shared__ int wprog[NL], wdone;                                     // worker's progress (rows), worker finished
     // virtual job = (job, segment): segment s of job j is slot j * smax + s, so the segments of a job spread over the XCDs
-    const int vjob = blockIdx.x + 8 * blockIdx.z, lane = threadIdx.x & 63;
-    const int role = UNI((int)threadIdx.x >> 6);                          // 0 worker, 1 fetcher
-    const int wave = blockIdx.y;
+    const int vjob = WG1 ? (int)blockIdx.x : (int)(blockIdx.x + 8 * blockIdx.z), lane = threadIdx.x & 63;
+    const int role = WG1 ? 0 : UNI((int)threadIdx.x >> 6);               // 0 worker, 1 fetcher
+    const int wave = WG1 ? UNI((int)threadIdx.x >> 6) : (int)blockIdx.y;
+    const int lw = WG1 ? wave : 0, wr = WG1 ? (wave + 1) % NW : 0;       // this wave's LDS slot, its right neighbour's
     if (vjob >= jb.njobs_launched * jb.smax) return;
     const int job = vjob / jb.smax;
     const SegDesc *const sd = jb.seg + (size_t)job * SEG_MAX + (vjob % jb.smax);
@@ -1112,8 +1120,9 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     unsigned *const chk_w = jb.chk + (((size_t)job * (SEG_MAX + 1) + sd->s) * 2 + 0) * (size_t)jb.NC;       // [s][0]: this segment after its warm-up
     unsigned *const chk_t = jb.chk + (((size_t)job * (SEG_MAX + 1) + sd->s + 1) * 2 + 1) * (size_t)jb.NC;   // [s + 1][1]: what the next one must match
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x < V4_RB) { rP[threadIdx.x] = 0; rM[threadIdx.x] = 0; }
-    if (threadIdx.x == 0) { wprog = 0; wdone = 0; }
+    for (int i = threadIdx.x; i < NL * RB; i += blockDim.x) { (&rP[0][0])[i] = 0; (&rM[0][0])[i] = 0; }   // (another work-group's words of this launch may lie here)
+    if (threadIdx.x < NL) wprog[threadIdx.x] = 0;
+    if (threadIdx.x == 0) wdone = 0;
     __syncthreads();
 
     const int wl = (wave + NW - 1) % NW;
@@ -1133,13 +1142,13 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 #define LLD(REF) __hip_atomic_load(&(REF), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 #define LST(REF, V) __hip_atomic_store(&(REF), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 
-    if (role == 1) {
+    if (!WG1 && role == 1) {
         // ---- fetcher
         // One poll = one L2 round trip (the abort flag is looked at every 16th poll, in the same batch of loads); the lag of
         // a worker behind its neighbour is this loop's period, and it is paid NW - 1 times per lap of the ring of waves.
         for (unsigned it = 0;; ++it) {
             if (UNI(LLD(wdone))) break;
-            const int wx = UNI(LLD(wprog));
+            const int wx = UNI(LLD(wprog[lw]));
             const int r = wx - 1 + lane;                                          // row wx needs words of row wx - 1 too
             const bool inr = r >= 0 && r < L;
             unsigned long long p = 0, q = 0;
@@ -1149,8 +1158,8 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             if (inr) {
                 const unsigned tagr = tagbase | (unsigned)(r + 1);
                 if (TAGOF(p) == tagr && TAGOF(q) == tagr) {
-                    LST(rP[r & (V4_RB - 1)], p);
-                    __hip_atomic_store(&rM[r & (V4_RB - 1)], q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // P before M: M's tag vouches for both
+                    LST(rP[lw][r & (RB - 1)], p);
+                    __hip_atomic_store(&rM[lw][r & (RB - 1)], q, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // P before M: M's tag vouches for both
                 }
             }
             // (no time-out of its own: the worker has one, and its end -- wdone -- or the job's abort flag end this loop)
@@ -1174,8 +1183,8 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             int4 p_ = make_int4(PWR_BIG / 2, PWR_BIG / 2, PWR_BIG / 2, PWR_BIG / 2);             \
             int4 q_ = make_int4(PWR_BIG / 2, 0, PWR_BIG / 2, 0);                                 \
             if (y_ <= hi) { p_ = rec2[2 * (y_ - lo)]; q_ = rec2[2 * (y_ - lo) + 1]; }            \
-            ldsS1[SLOT][0][lc + i] = p_.x; ldsS1[SLOT][1][lc + i] = p_.y;                        \
-            ldsS1[SLOT][2][lc + i] = p_.z; ldsS1[SLOT][3][lc + i] = p_.w;                        \
+            ldsS1[lw][SLOT][0][lc + i] = p_.x; ldsS1[lw][SLOT][1][lc + i] = p_.y;                        \
+            ldsS1[lw][SLOT][2][lc + i] = p_.z; ldsS1[lw][SLOT][3][lc + i] = p_.w;                        \
             AU[i] = q_.x; AG[i] = q_.y; AI[i] = q_.z;                                            \
         }                                                                                        \
         const int yq_ = lo + (MSX) * MS - 1;                                                     \
@@ -1242,7 +1251,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     {                                                                                            \
         a_prev = a; Bx_prev = Bx;                                                                \
         ++x;                                                                                     \
-        if (lane == 0) LST(wprog, x);                                                            \
+        if (lane == 0) LST(wprog[lw], x);                                                            \
         if (x < L) {                                                                             \
             if ((x >> 6) != blk) V4_ROTATE_BLOCK()                                               \
             a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);                             \
@@ -1251,6 +1260,10 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     }
 
     DG_DECL
+#ifdef PWR_DIAG
+    unsigned long long *const tl = jb.diag + ((size_t)job * 32 + 31) * 4096 + (size_t)(sd->s * NW + wave) * 6;   // the segment's time line
+    if (lane == 0 && sd->s * NW + wave < 680) { tl[0] = t_real0; tl[1] = __builtin_amdgcn_s_memrealtime(); tl[2] = 0; }
+#endif
     // A wave takes its next macro-strip over at the 16-row boundary BEFORE the strip's first row with work: in the rows in
     // between every cell of the strip lies past the band's end and is masked by the right-hand guard, which leaves exactly the
     // virtual extension G + Ptot in Mprev (PW:285-295) -- but the strip starts with a whole group of straight-line rows, not
@@ -1270,6 +1283,9 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
     while (x < L && !dead) {
         ran_prev = UNI(ran_prev); gacc = UNI(gacc); nacc = UNI(nacc); blk = UNI(blk); ms = UNI(ms); cs = UNI(cs); gleft = UNI(gleft);
         x = UNI(x);
+#ifdef PWR_DIAG
+        if (ran_prev && !dg_tl2) { dg_tl2 = __builtin_amdgcn_s_memrealtime(); if (lane == 0 && sd->s * NW + wave < 680) { tl[2] = dg_tl2; tl[5] = (unsigned long long)x; } }
+#endif
         // ---- fast path: a RUN of ordinary rows (flagged by the gather), from x to the first row that is not ordinary.
         // What a row needs beyond its cells is reduced to the hand-over: the left neighbour's self-validating words are
         // taken from the ring before the scan and checked after it, where the wave waits if they are not there yet -- so it
@@ -1296,7 +1312,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 unsigned dcs = min(dca >> 24, 3u) * (unsigned)(MS * 4);
                 if ((x >> 4) != gacc) { V4_FLUSH() gacc = x >> 4; }
                 V4_ALIGN_ACC(x & 15)
-                if (lane == 0) LST(wprog, x);                                    // the fetcher looks at the rows [x - 1, x + 63)
+                if (lane == 0) LST(wprog[lw], x);                                    // the fetcher looks at the rows [x - 1, x + 63)
                 unsigned mlast_v = 0;                                            // M_last(x-1) of the left neighbour
                 if (first) {
                     // The wave's first row on this macro-strip (it has just taken it over, or the band has just reached it).
@@ -1317,7 +1333,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     const unsigned t0 = V3_TICKS();
                     for (unsigned spin = 1;; ++spin) {
                         eT = GLD(PTOT_PTR(a_prev, Bx_prev, x - 1));
-                        eM = LLD(rM[(x - 1) & (V4_RB - 1)]);
+                        eM = LLD(rM[lw][(x - 1) & (RB - 1)]);
                         if (UNI(TAGOF(eT)) == tagp && (!needM || UNI(TAGOF(eM)) == tagp)) break;
                         if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
                         __builtin_amdgcn_s_sleep(1);
@@ -1338,12 +1354,12 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     ran_prev = 1;
                 } else if ((bMm >> (x & 63)) & 1ull) {
                     const unsigned tagp = tagbase | (unsigned)x;
-                    unsigned long long w_ = LLD(rM[(x - 1) & (V4_RB - 1)]);
+                    unsigned long long w_ = LLD(rM[lw][(x - 1) & (RB - 1)]);
                     if (UNI(TAGOF(w_)) != tagp) {                                   // (bounded by a time-out that flags the job)
                         DG_T0()
                         const unsigned t0 = V3_TICKS();
                         for (unsigned spin = 1;; ++spin) {
-                            w_ = LLD(rM[(x - 1) & (V4_RB - 1)]);
+                            w_ = LLD(rM[lw][(x - 1) & (RB - 1)]);
                             if (UNI(TAGOF(w_)) == tagp) break;
                             if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
                             __builtin_amdgcn_s_sleep(1);
@@ -1356,7 +1372,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                 int ycol[C];                                                     // absolute columns of this lane's cells
 #pragma unroll
                 for (int i = 0; i < C; ++i) ycol[i] = lo + ms * MS + lc + i;
-                const char *const stab = (const char *)&ldsS1[cs][0][lc];          // + dcs: the row's substitution scores S_b - G
+                const char *const stab = (const char *)&ldsS1[lw][cs][0][lc];          // + dcs: the row's substitution scores S_b - G
                 int sgr[C];
                 {
                     const int *const srow0 = (const int *)(stab + __builtin_amdgcn_readlane((int)dcs, x & 63));
@@ -1389,8 +1405,23 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     if (!dg_ts1 && x >= 1024) dg_ts1 = __builtin_amdgcn_s_memrealtime();
                     if (!dg_ts2 && x >= 2048) dg_ts2 = __builtin_amdgcn_s_memrealtime();
 #endif
+                    if (WG1) {
+                        // the ring slots of this group's rows hold the rows RB earlier: is the right neighbour past them?
+                        const int need = g0 + 16 - RB + 2;
+                        if (need > 0 && UNI(LLD(wprog[wr])) < need) {
+                            DG_T0()
+                            const unsigned t0 = V3_TICKS();
+                            for (unsigned spin = 1;; ++spin) {
+                                if (UNI(LLD(wprog[wr])) >= need) break;
+                                if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
+                            DG_ADD(dg_wait_setup)
+                            if (dead) break;
+                        }
+                    }
                     unsigned long long *const gq0 = gmy + 2 * (size_t)g0;
-                    const unsigned long long *const ringM = &rM[g0 & (V4_RB - 1)], *const ringP = &rP[g0 & (V4_RB - 1)];   // the group's 16 consecutive slots
+                    const unsigned long long *const ringM = &rM[lw][g0 & (RB - 1)], *const ringP = &rP[lw][g0 & (RB - 1)];   // the group's 16 consecutive slots
                     auto group_row = [&](const int r, auto cls_) __attribute__((always_inline)) {
                         constexpr int CLS = decltype(cls_)::value;                 // 0 INTERIOR, 1 RIGHT, 2 LEFT, 3 run-time flags
                         const int xr = g0 + r;
@@ -1473,7 +1504,10 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                         mlast_v = (unsigned)fM;
                         if (lane == 63) {
                             GST2(gq0 + 2 * r, P_end_v, tagx);
-                            GST2(gq0 + 2 * r + 1, Mprev[C - 1], tagx);
+                            if (WG1) {
+                                LST(rP[wr][(g0 + r) & (RB - 1)], ((unsigned long long)tagx << 32) | (unsigned)P_end_v);
+                                LST(rM[wr][(g0 + r) & (RB - 1)], ((unsigned long long)tagx << 32) | (unsigned)Mprev[C - 1]);   // P before M: M's tag vouches for both
+                            } else GST2(gq0 + 2 * r + 1, Mprev[C - 1], tagx);
                         }
                     };
                     int r_end = r_e;
@@ -1542,7 +1576,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 #pragma unroll
                         for (int i = 0; i < C; ++i) sgr[i] = srow0[i];
                     }
-                    if (lane == 0) LST(wprog, x);
+                    if (lane == 0) LST(wprog[lw], x);
                 }
                 a_prev = af_done; Bx_prev = min(B, W - af_done);
                 if (dead) break;
@@ -1551,7 +1585,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
                     a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
                     sx = __builtin_amdgcn_readlane(scur, x & 63);
                 }
-                if (lane == 0) LST(wprog, x);
+                if (lane == 0) LST(wprog[lw], x);
                 continue;
             }
         }
@@ -1601,7 +1635,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             }
             x = xs;
             ran_prev = 0;
-            if (lane == 0) LST(wprog, x);
+            if (lane == 0) LST(wprog[lw], x);
             if (x < L) {
                 if ((x >> 6) != blk) V4_ROTATE_BLOCK()
                 a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
@@ -1616,6 +1650,14 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         const bool needM = x > 0 && yq >= a_prev && yq < a_prev + Bx_prev;
         const bool needT = x > 0 && ((yq >= a_prev + Bx_prev) || !ran_prev);
         unsigned ePx = 0, ePy = 0, eMy = 0, eTx = 0;
+        if (WG1 && x - RB + 2 > 0) {
+            const unsigned t0 = V3_TICKS();
+            for (unsigned spin = 1; UNI(LLD(wprog[wr])) < x - RB + 2; ++spin) {
+                if ((spin & 1023u) == 0 && (V3_TICKS() - t0 > V3_TIMEOUT_TICKS || UNI(GLD(abortf)))) { dead = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (dead) break;
+        }
         {
             const unsigned tagx = tagbase | (unsigned)(x + 1), tagp = tagbase | (unsigned)x;
 #ifdef PWR_DIAG
@@ -1624,8 +1666,8 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
             DG_T0()
             const unsigned t0 = V3_TICKS();
             for (unsigned spin = 1;; ++spin) {
-                const unsigned long long eQ = LLD(rM[x & (V4_RB - 1)]), eP = LLD(rP[x & (V4_RB - 1)]);
-                const unsigned long long eM = LLD(rM[(x - 1) & (V4_RB - 1)]), eT = needT ? GLD(PTOT_PTR(a_prev, Bx_prev, x - 1)) : 0ull;
+                const unsigned long long eQ = LLD(rM[lw][x & (RB - 1)]), eP = LLD(rP[lw][x & (RB - 1)]);
+                const unsigned long long eM = LLD(rM[lw][(x - 1) & (RB - 1)]), eT = needT ? GLD(PTOT_PTR(a_prev, Bx_prev, x - 1)) : 0ull;
                 ePx = UNI((unsigned)eP); ePy = UNI((unsigned)eQ); eMy = UNI((unsigned)eM); eTx = UNI((unsigned)eT);
                 const bool ready = (!needP || (UNI(TAGOF(eP)) == tagx && UNI(TAGOF(eQ)) == tagx)) &&
                                    (!needM || UNI(TAGOF(eM)) == tagp) && (!needT || UNI(TAGOF(eT)) == tagp);
@@ -1663,7 +1705,7 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
 #pragma unroll
         for (int i = 0; i < C; ++i) {
             const int pm1 = i ? (int)Mprev[i > 0 ? i - 1 : 0] : pm1_0;
-            const int d = pm1 + ldsS1[cs][sxc][lc + i];
+            const int d = pm1 + ldsS1[lw][cs][sxc][lc + i];
             const int u = (int)Mprev[i] + ug[i];
             accC[i] = (accC[i] << 1) | ((d <= u) ? 1u : 0u);
             const int t3 = min(min(d, u), ig[i]);
@@ -1705,7 +1747,11 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         nacc = (x & 15) + 1;
         if (lane == 63) {
             GST(gmy + 2 * (size_t)x, P_end, x);
-            GST(gmy + 2 * (size_t)x + 1, Mprev[C - 1], x);
+            if (WG1) {
+                const unsigned long long tg_ = (unsigned long long)(tagbase | (unsigned)(x + 1)) << 32;
+                LST(rP[wr][x & (RB - 1)], tg_ | (unsigned)P_end);
+                LST(rM[wr][x & (RB - 1)], tg_ | (unsigned)Mprev[C - 1]);
+            } else GST(gmy + 2 * (size_t)x + 1, Mprev[C - 1], x);
         }
         ran_prev = 1;
         V4_CHK_STORE(x + 1, a, a + Bx)
@@ -1721,7 +1767,10 @@ __global__ __launch_bounds__(128) void k_fill_v3(DState st, JobBufs jb)
         dgp[12] = dg_log; dgp[8] = dg_cyc_gen16; dgp[9] = dg_ts1; dgp[10] = dg_ts2; dgp[11] = dg_cyc_int;
     }
 #endif
-    if (lane == 0) LST(wdone, 1);                                                    // releases the fetcher
+#ifdef PWR_DIAG
+    if (lane == 0 && sd->s * NW + wave < 680) { tl[3] = __builtin_amdgcn_s_memrealtime(); tl[4] = (unsigned long long)L | ((unsigned long long)(dg_wait_fast + dg_wait_gen + dg_wait_setup) << 20); }
+#endif
+    if (lane == 0) { LST(wprog[lw], 0x7fffffff); LST(wdone, 1); }                     // releases the left neighbour / the fetcher
     if (dead) {
         // A wave gave up waiting (its neighbour's work-group is not running: the GPU is shared, or more contexts are in
         // flight than it can hold at once).  The job is flagged -- its siblings leave, trace and commit skip it -- and the
@@ -3043,11 +3092,10 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
     // DP reads or either commit writes) are disjoint, with a margin for the column a commit may open at its interval's edge.
     // The DP depends on absolute positions only through the clamps at the MSA's edges, which disjoint intervals rule out
     // (commutation probe), so realigning j after i gives the state the reference reaches with j before i.
-    __shared__ int sk_lo[128], sk_hi[128];                                        // slots at the ends of the stale jobs' intervals
+    __shared__ int sk_row[128];                                                   // rows of the stale jobs
     int live_done = 0, live_all = 0, nskip = 0, ahead_n = 0;
     unsigned long long done_mask = 0;
     bool stopped = false;
-    const int *order_c = cur_order(st);
     for (int j = 0; j < njobs; ++j) {
         JobMeta *m = &jb.meta[j];
         if (!m->active) break;                                                    // the batch ends here
@@ -3079,17 +3127,23 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
             }
             bool good = validate_job(st, jb, j, sh, s_i);                         // (on success lo / hi are in today's numbering)
             if (good && nskip > 0) {
-                order_c = cur_order(st);
+                // The interval a stale row WILL be realigned over is the one its next gather takes from the state as it is
+                // now (the columns its gather of this batch saw at the interval's ends may since have moved against its
+                // bases: an earlier commit of the batch opened or emptied columns in between).  A commit of a disjoint
+                // interval only renumbers it.
+                const int Wn = h->W;
                 for (int t = 0; t < nskip && good; ++t) {
-                    const int lo_s = st.rank[sk_lo[t]], hi_s = st.rank[sk_hi[t]];
-                    const bool alive = lo_s >= 0 && lo_s < h->W && hi_s >= 0 && hi_s < h->W && order_c[lo_s] == sk_lo[t] && order_c[hi_s] == sk_hi[t];
-                    if (!alive || !(m->hi + 2 < lo_s || hi_s + 2 < m->lo)) good = false;
+                    const int ks = sk_row[t], Ls = st.rowlen[ks];
+                    const long long offs = st.rowoff[ks];
+                    const int w0 = st.rank[st.pos[offs]], wL = st.rank[st.pos[offs + Ls - 1]];
+                    const int lo_s = max(0, max(0, w0 - st.H) - 1), hi_s = min(Wn - 1, max(0, wL - st.H) + st.B - 1);
+                    if (!(m->hi + 2 < lo_s || hi_s + 2 < m->lo)) good = false;
                 }
             }
             if (!good) {
                 if (threadIdx.x == 0) h->stop = 1;
                 if (nskip >= 128) { stopped = true; continue; }
-                if (threadIdx.x == 0) { sk_lo[nskip] = m->slot_lo; sk_hi[nskip] = m->slot_hi; }
+                if (threadIdx.x == 0) sk_row[nskip] = m->k;
                 nskip += 1;
                 __syncthreads();
                 continue;
@@ -3218,7 +3272,7 @@ struct pwr_ctx {
     long long sumL = 0;
     int Lmax = 0;
     // options
-    int window = 8;
+    int window = 3;
     double batch_ema = 1.0;               // running mean of rows committed per batch (sizes the next one)
     int profile = 0;
     unsigned gather_tag = 0;              // launch counter of the gather
@@ -3231,10 +3285,11 @@ struct pwr_ctx {
     int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP; cross-check and fallback)
     unsigned trace_epoch = 0;             // k_trace_par launch counter (22 bits)
     unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
-    int wp_waves = 9;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane
-    int seg_rows = 1024;                  // k_fill_v3: a DP is filled in segments of about this many rows, side by side (0: in one piece)
-    int seg_max = 16;                     // ... at most this many per DP (<= SEG_MAX)
-    int warm_pct = 200;                   // ... each warmed up while the band moves by this many percent of the bandwidth
+    int wp_waves = 5;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane (5: measured best with segments side by side)
+    int one_wg = 0;                       // k_fill_v3: the waves of a segment as one work-group (hand-over through LDS); 0: one work-group per wave
+    int seg_rows = 160;                   // k_fill_v3: a DP is filled in segments of about this many rows, side by side (0: in one piece)
+    int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
+    int warm_pct = 180;                   // ... each warmed up while the band moves by this many percent of the bandwidth
     // stats
     pwr_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -3654,14 +3709,24 @@ static int launch_fill(pwr_ctx *c, int njobs)
         c->jb.njobs_launched = njobs;
         c->jb.stall_test = c->stall_test > 0 ? 1 : 0;
         if (c->stall_test > 0) c->stall_test -= 1;
-        const dim3 grid(8, c->wp_waves, (njobs * c->jb.smax + 7) / 8);     // one slot per (job, segment)
-        if (c->wp_waves == 17) hipLaunchKernelGGL((k_fill_v3<17, 1>), grid, dim3(128), 0, c->stream, c->st, c->jb);
-        else if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4>), grid, dim3(128), 0, c->stream, c->st, c->jb);
-        else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3>), grid, dim3(128), 0, c->stream, c->st, c->jb);
-        else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6>), grid, dim3(128), 0, c->stream, c->st, c->jb);
-        else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8>), grid, dim3(128), 0, c->stream, c->st, c->jb);
-        else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v3<9, 2>), grid, dim3(128), 0, c->stream, c->st, c->jb);
-        else hipLaunchKernelGGL((k_fill_v3<9, 4>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        const int nv = njobs * c->jb.smax;                                 // one slot per (job, segment)
+        const dim3 grid(8, c->wp_waves, (nv + 7) / 8);
+        const bool wg1 = c->one_wg && c->wp_waves <= 9 && c->B <= 1024;
+        if (wg1) {
+            // the waves of a segment as one work-group (LDS hand-over)
+            if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4, true>), dim3(nv), dim3(5 * 64), 0, c->stream, c->st, c->jb);
+            else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3, true>), dim3(nv), dim3(8 * 64), 0, c->stream, c->st, c->jb);
+            else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6, true>), dim3(nv), dim3(4 * 64), 0, c->stream, c->st, c->jb);
+            else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8, true>), dim3(nv), dim3(3 * 64), 0, c->stream, c->st, c->jb);
+            else hipLaunchKernelGGL((k_fill_v3<9, 2, true>), dim3(nv), dim3(9 * 64), 0, c->stream, c->st, c->jb);
+        }
+        else if (c->wp_waves == 17) hipLaunchKernelGGL((k_fill_v3<17, 1, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v3<9, 2, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else hipLaunchKernelGGL((k_fill_v3<9, 4, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         c->jb.stall_test = 0;
         if (c->jb.smax > 1 && c->jb.seg_rows > 0)
             hipLaunchKernelGGL(k_seg_check, dim3(njobs, c->jb.smax - 1), dim3(256), 0, c->stream, c->st, c->jb);
@@ -3759,7 +3824,7 @@ static int enqueue_batch(pwr_ctx *c)
 // device sequences the rows itself (Hdr::next_row); the host keeps PWR_INFLIGHT batches queued and looks at a copy of the
 // header that trails by that many batches, so no launch waits for a round trip.  Batches enqueued after the slab's last row
 // was committed find nothing to do.
-static int realign_range(pwr_ctx *c, int k0, int n)
+static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
 {
     if (!c->h_ring) {
         void *p = nullptr;
@@ -3769,8 +3834,10 @@ static int realign_range(pwr_ctx *c, int k0, int n)
     }
     Hdr *ring = static_cast<Hdr *>(c->h_ring);
     const int kend = k0 + n;
-    {
-        // start the slab: rows [k0, kend), first batch sized like the host did before (the running mean carries over)
+    if (!resume) {
+        // start the slab: rows [k0, kend), first batch sized like the host did before (the running mean carries over).
+        // (After a regrow the slab goes on where it stood: the device's row pointer and its mask of rows already committed
+        // ahead of order stay as they are -- each row is realigned once per round, PW:1695.)
         int nb = (int)(c->batch_ema + 2.6);
         nb = std::max(1, std::min(nb, std::min(c->window, n)));
         for (int j = 1; j < nb; ++j)
@@ -3807,7 +3874,7 @@ static int realign_range(pwr_ctx *c, int k0, int n)
             long long growth = 0;
             for (int j = 0; j < c->window && h.next_row + j < kend; ++j) growth += c->rowlen[h.next_row + j];
             if ((rc = grow_state(c, growth))) return rc;
-            return realign_range(c, h.next_row, kend - h.next_row);
+            return realign_range(c, h.next_row, kend - h.next_row, true);
         }
         if (h.next_row >= kend) break;
         if (h.ncommitted == 0 && most < 2LL * n + 64) ++most;                   // ... except one whose first job stalled (it is repeated by k_fill_v2)
@@ -3947,6 +4014,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     // (test hooks: where the launch counters behind the mailbox / hand-over tags stand, so that their wrap-around can be exercised)
     if (!strcmp(key, "fill_epoch")) { if (value < 0 || value >= (1 << 15)) return PWR_ERR_ARG; c->fill_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "trace_epoch")) { if (value < 0 || value >= (1 << 14)) return PWR_ERR_ARG; c->trace_epoch = (unsigned)value; return PWR_OK; }
+    if (!strcmp(key, "onewg")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->one_wg = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_rows")) { if (c->on_device || value < 0 || value > 1000000) return PWR_ERR_ARG; c->seg_rows = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_pct")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->warm_pct = (int)value; return PWR_OK; }
@@ -3965,6 +4033,7 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "force64")) *value = c->force64;
     else if (!strcmp(key, "slack")) *value = c->cap_slack;
     else if (!strcmp(key, "waves")) *value = c->wp_waves;
+    else if (!strcmp(key, "onewg")) *value = c->one_wg;
     else if (!strcmp(key, "seg_rows")) *value = c->seg_rows;
     else if (!strcmp(key, "seg_max")) *value = c->seg_max;
     else if (!strcmp(key, "warm_pct")) *value = c->warm_pct;

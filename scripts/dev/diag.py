@@ -8,9 +8,10 @@ from repeatresolver_amd import datagen as dg
 from repeatresolver_amd.realigner import PWReAligner
 wl = sys.argv[1] if len(sys.argv) > 1 else "tree_medium"
 waves = int(os.environ.get("WAVES", "9"))
-ks = [int(v) for v in sys.argv[2:]] or [0, 1, 2]
+ks = [int(v) for v in sys.argv[2:] if "=" not in v] or [0, 1, 2]
+opts = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[2:] if "=" in a}
 rows = [bytes(r) for r in dg.make_msa(wl)]
-g = PWReAligner(rows, bandwidth=1000, window=1, waves=waves)
+g = PWReAligner(rows, bandwidth=1000, window=1, waves=waves, **opts)
 g.trim_ends(); g.total_score()
 lib = _lib.load()
 lib.pwr_debug_fill_diag.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64)]

@@ -33,7 +33,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "all"
 if what in ("all", "toy"):
     for name, bw in (("toy_b_b1000", 1000), ("toy_a_b1000", 1000), ("toy_a_b50", 50), ("lowcov_b300", 300), ("deep_b200", 200)):
         rows = split_rows(golden_input(name))
-        for sr, wp in ((128, 200), (256, 150), (128, 20)):
+        for sr, wp in ((128, 200), (128, 20)):
             print(name, "seg_rows", sr, "warm_pct", wp, flush=True)
             parity(rows, bw, 60, seg_rows=sr, seg_max=16, warm_pct=wp)
 if what in ("all", "medium"):
