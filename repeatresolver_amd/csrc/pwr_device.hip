@@ -146,7 +146,7 @@ struct JobBufs {
     int wpNW, wpMS;                // geometry of the wave pipeline the descriptors are made for
     unsigned *lastM;               // [njobs][NC]     scores of the last DP row (wave-pipeline fill)
     unsigned long long *gmb;       // [njobs][NW][gstride][2] k_fill_v3: {P_end, tag}, {M_last, tag} per wave and DP row (segments side by side)
-    SegDesc *seg;                  // [njobs][SEG_MAX] plan of the fill (k_gather_b)
+    SegDesc *seg;                  // [njobs][SEG_MAX] plan of the fill (plan_segments, with k_gather_c)
     unsigned *chk;                 // [njobs][SEG_MAX + 1][2][NC] scores of the row before segment s: [0] as s has them after its warm-up, [1] as s - 1 ends
     int smax, seg_rows, warm_cols; // at most smax segments per job, of about seg_rows own rows, warmed up over warm_cols columns of band movement
     int gstride;                   // rows per wave of a job's mailbox area
@@ -283,8 +283,8 @@ __device__ __forceinline__ int gather_row_of(const Hdr *hd, int job, int *boff_o
     return kk;
 }
 
-// gather, step a: ordinals of the share's bases (TheWay, PW:647-705), row descriptors and reference cell count for them, marks
-// of the share's columns cleared; share 0 writes the job's header.
+// gather, step a: ordinals of the share's bases (TheWay, PW:647-705), row descriptors and reference cell count for them, the
+// marks of the row's own symbols; share 0 writes the job's header.
 __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, const int *jobrows)
 {
     const int job = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
@@ -309,15 +309,21 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, c
     const int lo = max(0, a0 - 1), hi = min(W - 1, aL + B - 1);
     const int n = hi - lo + 1;
     const int x0 = (int)((long long)L * g / GATHER_G), x1 = (int)((long long)L * (g + 1) / GATHER_G);
-    const int i0 = (int)((long long)n * g / GATHER_G), i1 = (int)((long long)n * (g + 1) / GATHER_G);
+    // The marks of the row's own symbols (base + 1 where it has a base, 0 where it has '-', 7 in a blank run between two of
+    // its segments): the share clears and sets the columns from its first base up to the next share's first base -- Way[] is
+    // increasing, so the shares' column ranges tile the interval and nobody waits for anybody.
     uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
-    for (int i = i0 + tid; i < i1; i += GATHER_NT) mark[i] = 0;
+    const int c0 = g == 0 ? lo : st.rank[st.pos[off + min(x0, L - 1)]], c1 = (g == GATHER_G - 1 || x1 >= L) ? hi + 1 : st.rank[st.pos[off + x1]];
+    (void)n;
+    for (int i = c0 - lo + tid; i < c1 - lo; i += GATHER_NT) mark[i] = 0;
+    __syncthreads();
     unsigned long long mycells = 0;
     uint4 *desc = jb.desc + (size_t)job * jb.Lmax;
     const int NWg = jb.wpNW, MSg = jb.wpMS;
     for (int x = x0 + tid; x < x1; x += GATHER_NT) {
         const int wx = st.rank[st.pos[off + x]];
         way[x] = wx;
+        mark[wx - lo] = (uint8_t)(st.seq[off + x] + 1);
         const int ax = max(0, wx - H), bx = min(B, W - ax);
         mycells += (unsigned long long)bx;                                          // cells of DP row x, PW:1496-1499
         // Row descriptors for the wave-pipeline fills: what every wave would otherwise recompute per DP row (anf < 2^24,
@@ -346,6 +352,16 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, c
             if (w < 16) fl |= (unsigned long long)bits << (4 * w); else fl2 |= bits << (4 * (w - 16));
         }
         desc[x] = make_uint4((unsigned)ax | ((unsigned)st.seq[off + x] << 24), (unsigned)fl, (unsigned)(fl >> 32), fl2);
+    }
+    {
+        // blank runs between the row's segments (rows read with interior blanks, until their first realignment)
+        const int nbk = st.nbrk[k];
+        const int *bxs = st.brkx + st.brkoff[k];
+        for (int t = tid; t < nbk; t += GATHER_NT) {
+            const int b = bxs[t];
+            if (b >= x0 && b < x1)
+                for (int y = st.rank[st.pos[off + b]] + 1; y < st.rank[st.pos[off + b + 1]]; ++y) mark[y - lo] = 7;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) mycells += __shfl_xor(mycells, o);
     __shared__ unsigned long long s_cells[GATHER_NT / 64];
@@ -431,31 +447,6 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
     }
 }
 
-// gather, step b: the row's own symbols marked in the interval (bases of the share's rows; blank runs between segments: 7);
-// the share after the last one plans the job's fill
-__global__ __launch_bounds__(GATHER_NT) void k_gather_b(DState st, JobBufs jb)
-{
-    const int job = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
-    if (g == GATHER_G) { plan_segments(st, jb, job); return; }
-    const JobMeta *m = &jb.meta[job];
-    if (!m->active || m->L <= 0) return;
-    const int L = m->L, k = m->k, lo = m->lo;
-    const long long off = st.rowoff[k];
-    const int *way = jb.way + (size_t)job * jb.Lmax;
-    uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
-    const int x0 = (int)((long long)L * g / GATHER_G), x1 = (int)((long long)L * (g + 1) / GATHER_G);
-    for (int x = x0 + tid; x < x1; x += GATHER_NT) mark[way[x] - lo] = (uint8_t)(st.seq[off + x] + 1);
-    if (g == 0) {
-        // blank runs between the row's segments (rows read with interior blanks, until their first realignment)
-        const int nb = st.nbrk[k];
-        const int *bx = st.brkx + st.brkoff[k];
-        for (int t = tid; t < nb; t += GATHER_NT) {
-            const int b = bx[t];
-            for (int y = way[b] + 1; y < way[b + 1]; ++y) mark[y - lo] = 7;
-        }
-    }
-}
-
 // gather, step c: Columns_Downdater (PW:1172-1201) into job-private DP inputs for the share's columns.  The prefix sums G run
 // over the whole interval: every share first publishes the sum over its own columns (with the launch's tag), then adds up
 // the shares before it -- they only depend on their own columns, so nobody waits long.  The last share finishes the header.
@@ -466,6 +457,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_c(DState st, JobBufs jb)
     __shared__ unsigned long long s_u[GATHER_NT / 64];
     __shared__ unsigned s_carry, s_covl;
     const int job = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    if (g == GATHER_G) { plan_segments(st, jb, job); return; }                       // (the share after the last one plans the job's fill)
     JobMeta *m = &jb.meta[job];
     if (!m->active || m->L <= 0) return;
     const int L = m->L, lo = m->lo, hi = m->hi, W = m->W, B = st.B;
@@ -3802,8 +3794,7 @@ static int enqueue_batch(pwr_ctx *c)
     int rc;
     c->jb.gather_tag = ++c->gather_tag;
     hipLaunchKernelGGL(k_gather_a, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids);
-    hipLaunchKernelGGL(k_gather_b, dim3(n, GATHER_G + 1), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
-    hipLaunchKernelGGL(k_gather_c, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
+    hipLaunchKernelGGL(k_gather_c, dim3(n, GATHER_G + 1), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
     if ((rc = launch_fill(c, n))) return rc;
     hipLaunchKernelGGL(k_fill64, dim3(n), dim3(F64_NT), 0, c->stream, c->st, c->jb);       // jobs the gather flagged wide (none, normally)
     if (c->par_trace) {

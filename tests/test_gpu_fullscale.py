@@ -109,6 +109,125 @@ def test_config3_distributed_stress_prefix_and_epoch_wrap(oracle):
     _prefix_parity("distributed_stress", 8, 112, oracle, fill_epoch=(1 << 15) - 30, others=(20000, 40194))
 
 
+def _sha_rows(rows):
+    h = hashlib.sha256()
+    for r in rows:
+        h.update(r)
+        h.update(b"\n")
+    return h.hexdigest()
+
+
+def _rounds_fixture():
+    with open(os.path.join(GOLDEN, "tree_default_rounds.json")) as f:
+        fx = json.load(f)
+    assert fx["rounds"], "tests/golden/tree_default_rounds.json holds no round yet (oracle/gen_fullscale.py)"
+    return fx
+
+
+def test_config2_every_round_against_the_reference():
+    """BASELINE.json configs[1], "run to convergence, bit-exact check": tests/golden/tree_default_rounds.json holds, for every
+    round the unmodified reference ran on the full-size MSA (13 510 x 136 477; oracle/gen_fullscale.py, 35-45 minutes of one
+    CPU core per round), its score line and the sha256 of the file it had just rewritten (PW:1741).  The GPU path is followed
+    through the same rounds: total score and exported text of every round, and the stop rule (PW:1742) when the fixture
+    reaches the reference's last, non-improving round."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    fx = _rounds_fixture()
+    rows = [bytes(r) for r in dg.make_msa("tree_default")]
+    assert _sha_rows(rows) == fx["input_sha256"], "the seeded generator drifted"
+    g = PWReAligner(rows, bandwidth=fx["bandwidth"])
+    del rows
+    g.trim_ends()
+    best = g.total_score()
+    for r in fx["rounds"]:
+        g.realign_round()
+        tot = g.total_score()
+        assert tot == r["score"], (r["round"], tot, r["score"])
+        assert (tot < best) == r["improved"], r["round"]
+        if not r["improved"]:
+            break                                              # the reference stops here and writes nothing (PW:1742)
+        best = tot
+        assert g.dims() == (r["rows"], r["columns"]), r["round"]
+        assert _sha_rows(g.export_rows()) == r["output_sha256"], r["round"]
+    st = g.stats()
+    assert st["stalls"] == 0 and st["rows_wide"] == 0
+    g.close()
+
+
+def test_config2_cli_rounds_against_the_reference(tmp_path):
+    """The same through the drop-in binary: `PW_ReAligner in -o out -r 2` -- score lines and the bytes of the file after the
+    second round, both as the reference produced them."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import run_file
+    fx = _rounds_fixture()
+    n = min(2, len([r for r in fx["rounds"] if r["improved"]]))
+    ip, op = str(tmp_path / "in.msa"), str(tmp_path / "out.msa")
+    dg.write_msa(ip, dg.make_msa("tree_default"))
+    rc, lines = run_file(ip, op, bandwidth=fx["bandwidth"], max_rounds=n)
+    assert rc == 0
+    got = [l for l in lines if l.startswith("OverallScore")]
+    assert got[1:1 + n] == [r["score_line"] for r in fx["rounds"][:n]], got
+    h = hashlib.sha256()
+    with open(op, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    assert h.hexdigest() == fx["rounds"][n - 1]["output_sha256"]
+
+
+def test_config4_sections_of_the_benchmark_msa(oracle):
+    """BASELINE.json configs[3] at its real size: the benchmark MSA after one realignment round (checked against the
+    reference's digest of that round) is cut at its Window.py boundaries (parts = 6, Window.py:41-60); all six sections are
+    realigned side by side on the GPU for a slab of rows, and two of them are followed by the oracle row for row."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    from repeatresolver_amd.window import slice_sections, window_boundaries
+    fx = _rounds_fixture()
+    rows = [bytes(r) for r in dg.make_msa("tree_default")]
+    g = PWReAligner(rows, bandwidth=1000)
+    del rows
+    g.trim_ends()
+    g.realign_round()
+    real = g.export_rows()
+    g.close()
+    assert _sha_rows(real) == fx["rounds"][0]["output_sha256"]
+    bounds = window_boundaries(real, parts=6)
+    assert len(bounds) == 7 and bounds == sorted(bounds) and bounds[0] > 0 and bounds[-1] < len(real[0])
+    secs = slice_sections(real, bounds)
+    del real
+    T = len(secs[0])
+    n = 100
+    ctxs = []
+    for sec in secs:                                       # six contexts side by side on one GPU, one stream each
+        c = PWReAligner(sec, bandwidth=1000)
+        c.trim_ends()
+        c.total_score()
+        ctxs.append(c)
+    import threading
+    ths = [threading.Thread(target=c.realign_rows, args=(0, n)) for c in ctxs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for p in (1, 4):                                       # the oracle on the same section, the same rows
+        h = oracle.create(secs[p], 1000)
+        oracle.lib.pwo_trim(h)
+        for k in range(n):
+            assert oracle.lib.pwo_realign_row(h, k) == 0
+        oracle.lib.pwo_compact(h)
+        assert ctxs[p].dims() == (T, oracle.lib.pwo_width(h)), p
+        for k in list(range(n)) + [T - 1]:
+            assert ctxs[p].debug_row_columns(k) == oracle.row_columns(h, k), (p, k)
+        assert ctxs[p].total_score() == oracle.lib.pwo_total_score(h), p
+        st = ctxs[p].stats()
+        assert st["cells_reference"] == oracle.lib.pwo_cells(h), p
+        oracle.lib.pwo_destroy(h)
+    for p, c in enumerate(ctxs):
+        st = c.stats()
+        assert st["rows_committed"] == sum(1 for k in range(n) if any(ch in b"ACGT" for ch in secs[p][k])), p
+        assert st["stalls"] == 0, p
+        c.close()
+
+
 def test_config4_window_sections_of_a_realigned_msa(oracle):
     """BASELINE.json configs[3] at a size the oracle can follow: Window.py boundaries (parts = 6) of a realigned MSA,
     the six sections realigned side by side on the GPU, each equal to the oracle on the same section."""
@@ -213,8 +332,13 @@ def test_bench_two_ranks_rehearsal():
     import subprocess
     import sys
     from conftest import ROOT
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))                                  # a free port: two suites may share a box
+    port = sk.getsockname()[1]
+    sk.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--workload", "tree_medium", "--backend", "gloo", "--one-device"]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]

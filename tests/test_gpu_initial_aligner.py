@@ -223,3 +223,22 @@ def test_reads_longer_than_the_template(ia_oracle):
     _check(templ, reads, ia_oracle)
     templ2 = bytes(rng.choice(list(b"acgt")) for _ in range(2300))           # two words per lane
     _check(templ2, [bytes(rng.choice(list(b"acgt")) for _ in range(5000)), templ2 + templ2[:700]], ia_oracle)
+
+
+def test_bytes_other_than_the_four_bases_are_refused():
+    """The C ABI maps a base to its code with two bits of the character: anything but acgt / ACGT would alias one of them,
+    so pia_create and pia_align refuse it (the reference's reader leaves nothing else, IA:190-209)."""
+    import ctypes
+    from repeatresolver_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.pia_create(ctypes.byref(h), b"acgtnacgt", 9, 0) == -4            # PWR_ERR_INPUT
+    assert lib.pia_create(ctypes.byref(h), b"acgtAcGt", 8, 0) == 0
+    reads = b"acg-acgt"
+    off = (ctypes.c_longlong * 2)(0, len(reads))
+    al = (ctypes.c_int * len(reads))()
+    dist = (ctypes.c_int * 1)()
+    assert lib.pia_align(h, 1, reads, off, al, dist) == -4
+    reads = b"ACgtacgt"
+    assert lib.pia_align(h, 1, reads, off, al, dist) == 0 and dist[0] == 0 and list(al) == list(range(8))
+    lib.pia_destroy(h)

@@ -1,0 +1,163 @@
+"""-m gpu: the segmented fill (a DP filled as segments side by side, each warmed up from a free start and CHECKED against
+its predecessor), the chunked traceback without a hand-over chain, and the two advisor findings of round 2
+(commit ahead of a stale row whose interval has moved; rows committed ahead across a regrow).  Everything is compared with
+the CPU oracle (oracle/, pinned to the compiled reference by tests/golden)."""
+import numpy as np
+import pytest
+
+from conftest import golden_input, split_rows
+from test_gpu_parity import _row_by_row
+
+pytestmark = pytest.mark.gpu
+
+SEG_CASES = [("toy_b_b1000", 1000, 1), ("toy_a_b1000", 1000, 2), ("toy_a_b50", 50, 2), ("lowcov_b300", 300, 2),
+             ("deep_b200", 200, 1), ("holes_b300", 300, 2)]
+
+
+@pytest.mark.parametrize("seg_rows,warm_pct", [(128, 200), (64, 300), (256, 150)])
+@pytest.mark.parametrize("name,bw,rounds", SEG_CASES, ids=[c[0] for c in SEG_CASES])
+def test_segmented_fill_row_by_row(name, bw, rounds, seg_rows, warm_pct, oracle):
+    """Every realignment of the fixtures with their fills cut into small segments: same Way, entry column, placement, MSA."""
+    _row_by_row(name, bw, rounds, oracle, seg_rows=seg_rows, seg_max=64, warm_pct=warm_pct)
+
+
+@pytest.mark.parametrize("onewg", [0, 1])
+@pytest.mark.parametrize("waves", [3, 4, 5, 8, 9, 17])
+def test_segmented_fill_wave_geometries(waves, onewg, oracle):
+    """... with every macro-strip width, the waves of a segment as work-groups of their own or as one (17 waves: only the former)."""
+    _row_by_row("toy_b_b1000", 1000, 1, oracle, waves=waves, onewg=onewg, seg_rows=128, seg_max=64, warm_pct=200)
+    _row_by_row("lowcov_b300", 300, 2, oracle, waves=waves, onewg=onewg, seg_rows=128, seg_max=64, warm_pct=200)
+
+
+def test_failed_segment_check_repeats_the_row_in_one_piece(oracle):
+    """A warm-up that is far too short (a fifth of the bandwidth): the check of the segments' starts must catch it, the row
+    is realigned again with its fill in one piece, and the results are the reference's all the same."""
+    from repeatresolver_amd.realigner import PWReAligner
+    for name, bw in (("toy_b_b1000", 1000), ("deep_b200", 200)):
+        rows = split_rows(golden_input(name))
+        for window in (1, 4):
+            g = PWReAligner(rows, bandwidth=bw, window=window, seg_rows=128, seg_max=64, warm_pct=20)
+            g.trim_ends()
+            h = oracle.create(rows, bw)
+            oracle.lib.pwo_trim(h)
+            g.realign_round()
+            oracle.lib.pwo_realign_round(h)
+            assert g.total_score() == oracle.lib.pwo_total_score(h)
+            assert g.export_rows() == oracle.export(h)
+            st = g.stats()
+            assert 0 < st["seg_fails"] <= st["seg_jobs"], st
+            assert st["cells_reference"] == oracle.lib.pwo_cells(h)
+            assert st["rows_committed"] == sum(1 for k in range(len(rows)) if oracle.lib.pwo_row_length(h, k) > 0)
+            oracle.lib.pwo_destroy(h)
+            g.close()
+
+
+def test_cells_computed_count_the_warm_up_rows(oracle):
+    """pwr_stats.cells_computed (the numerator of bench.py's roofline figure) against the plan restated here: segment s of
+    a row owns the rows [x_s, x_{s+1}), x_s = floor(L s / S) rounded down to 64, and warms up from the last multiple of 64
+    whose base lies at least warm_cols columns left of base x_s; every row of it costs min(B, W - anf) cells."""
+    from repeatresolver_amd.realigner import PWReAligner
+    rows = split_rows(golden_input("toy_b_b1000"))
+    bw, H, sr, smax, wp = 1000, 500, 128, 64, 150
+    warm_cols = bw * wp // 100 + 2
+    g = PWReAligner(rows, bandwidth=bw, window=1, seg_rows=sr, seg_max=smax, warm_pct=wp)
+    g.trim_ends()
+    h = oracle.create(rows, bw)
+    lib = oracle.lib
+    lib.pwo_trim(h)
+    exp_cells = exp_segs = exp_jobs = 0
+    for k in range(40):
+        assert lib.pwo_realign_row(h, k) == 0
+        g.realign_row(k)
+        L = lib.pwo_dbg_L(h)
+        if L == 0:
+            continue
+        W = lib.pwo_dbg_W_at_fill(h)
+        way = np.ctypeslib.as_array(lib.pwo_dbg_way(h), (L,)).astype(np.int64)
+        cells = np.minimum(bw, W - np.maximum(0, way - H))
+        S = max(1, min((L + sr // 2) // sr, smax, L // 128))
+        xs = [(L * s // S) & ~63 for s in range(S)] + [L]
+        for s in range(S):
+            xb = 0
+            if s > 0:
+                cand = [c for c in range(0, xs[s], 64) if way[c] <= way[xs[s]] - warm_cols]
+                xb = cand[-1] if cand else 0
+            exp_cells += int(cells[xb:xs[s + 1]].sum())
+        if S > 1:
+            exp_jobs += 1
+            exp_segs += S
+    st = g.stats()
+    assert st["seg_fails"] == 0 and st["rows_recomputed"] == 0
+    assert (st["seg_jobs"], st["segs"]) == (exp_jobs, exp_segs)
+    assert st["cells_computed"] == exp_cells
+    assert st["cells_reference"] == lib.pwo_cells(h)
+    lib.pwo_destroy(h)
+    g.close()
+
+
+@pytest.mark.parametrize("ptrace", [0, 1, 2])
+def test_traceback_kernels_agree(ptrace, oracle):
+    """k_trace_wp (one wave), k_trace_par (64 chunks handing over top-down) and k_trace_blk (one wave per 64 rows, no
+    chain): the same placements row by row."""
+    _row_by_row("toy_b_b1000", 1000, 1, oracle, ptrace=ptrace)
+    _row_by_row("lowcov_b300", 300, 3, oracle, ptrace=ptrace)
+    _row_by_row("toy_a_b50", 50, 2, oracle, ptrace=ptrace, seg_rows=128)
+
+
+def test_commit_ahead_when_the_stale_rows_interval_has_moved(oracle):
+    """Advisor, round 2: a row can be stale because an earlier commit of the batch opened or emptied columns inside its band
+    interval; the interval its next gather takes is then no longer bounded by the columns the old one ended in, and a later
+    row must be tested against the interval as it is NOW before it commits ahead.  Low coverage makes rows slide (columns
+    open and empty by the dozen), a narrow band makes the margins matter, wide windows make commits ahead frequent; every
+    round of every seed is compared with the oracle."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    lib = oracle.lib
+    ahead = 0
+    for seed in range(12):
+        cfg = dg.SimConfig(kind="Distributed", copies=3, coverage=3, difference=0.03, repeat_len=2500, flank=600,
+                           length_scale=0.02, min_aligned=40, seed=100 + seed)
+        rows = [bytes(r) for r in dg.build_msa(dg.simulate(cfg))]
+        bw = (6, 10, 16, 24)[seed % 4]
+        g = PWReAligner(rows, bandwidth=bw, window=(16, 64)[seed % 2])
+        g.trim_ends()
+        h = oracle.create(rows, bw)
+        lib.pwo_trim(h)
+        for rnd in range(3):
+            g.realign_round()
+            lib.pwo_realign_round(h)
+            assert g.total_score() == lib.pwo_total_score(h), (seed, rnd)
+            assert g.export_rows() == oracle.export(h), (seed, rnd)
+        st = g.stats()
+        ahead += st["rows_ahead"]
+        assert st["cells_reference"] == lib.pwo_cells(h), seed
+        lib.pwo_destroy(h)
+        g.close()
+    assert ahead > 0
+
+
+def test_rows_committed_ahead_survive_a_regrow(oracle):
+    """Advisor, round 2: with no spare capacity (slack 0) the column arrays are regrown in the middle of a slab; the rows that
+    had been committed ahead of order before that must not be realigned a second time (PW:1695 visits a row once per round)."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    cfg = dg.SimConfig(kind="Tree", copies=6, coverage=12, difference=0.01, repeat_len=6000, flank=1500,
+                       length_scale=0.03, min_aligned=60, seed=31)
+    rows = [bytes(r) for r in dg.build_msa(dg.simulate(cfg))]
+    lib = oracle.lib
+    g = PWReAligner(rows, bandwidth=100, window=16, slack=0)
+    g.trim_ends()
+    h = oracle.create(rows, 100)
+    lib.pwo_trim(h)
+    live = sum(1 for k in range(len(rows)) if lib.pwo_row_length(h, k) > 0)
+    for rnd in range(3):
+        g.reset_stats()
+        g.realign_round()
+        lib.pwo_realign_round(h)
+        st = g.stats()
+        assert st["rows_committed"] == live, (rnd, st)
+        assert g.total_score() == lib.pwo_total_score(h)
+        assert g.export_rows() == oracle.export(h)
+    assert st["rows_ahead"] > 0
+    lib.pwo_destroy(h)
+    g.close()
