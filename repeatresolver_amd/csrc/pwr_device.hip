@@ -60,7 +60,8 @@ struct Hdr {                       // lives in device memory, one per context
     int speclen;                   // a speculative row may be this many percent longer than the batch's first row
     unsigned long long ahead;      // bit b: row next_row + b was committed ahead of an earlier, stale row it commutes with (its band
                                    // interval is disjoint from that row's), so the batches to come leave it out
-    int noseg_row, pad1;           // this row's segmented fill failed its check: its next fill runs in one piece (-1: none)
+    int noseg_row;                 // this row's segmented fill failed its check: its next fill runs in one piece (-1: none)
+    int need64;                    // > 0: a job needed the 64-bit fill lately; the host launches k_fill64 with the batches while this counts down
     unsigned long long dbg[32];    // phase timers of commit and trace (10 ns ticks), only written by builds with -DPWR_DIAG
 };
 #ifdef PWR_DIAG
@@ -158,6 +159,8 @@ struct JobBufs {
     int force64;                   // test hook: every job takes the 64-bit fill
     int evcap;                     // commits with more structural events than this renumber by a pass over the width (test hook; <= EVCAP)
     int gate_v2;                   // k_fill_v2 launched behind k_fill_v3: it runs only while Hdr::fallback > 0
+    int v2_follows, f64_follows;   // this batch's launches include the stand-in k_fill_v2 / the 64-bit k_fill64 (the host adds them when the
+                                   // header it last saw says they are wanted; a job that wanted one in a batch without it is repeated)
     int stall_test;                // test hook: job 0 of this k_fill_v3 launch pretends its neighbour never answers
     unsigned long long *diag;      // [njobs][32][4096] per-wave counters, switch events and a progress log of k_fill_v3 (only written when built with -DPWR_DIAG)
     int njobs_launched;
@@ -561,6 +564,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_c(DState st, JobBufs jb)
             m->maxS = mxt; m->cells = cs;
             // the wave pipeline works with absolute prefix sums G: their total (= bases in the interval) must stay below 2^29
             m->wide = (jb.force64 || !(bound < (unsigned long long)PWR_INF && carry < (1u << 29))) ? 1 : 0;   // -> k_fill64
+            if (m->wide) st.hdr->need64 = 65;
         }
     }
 }
@@ -1098,7 +1102,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
     const int job = vjob / jb.smax;
     const SegDesc *const sd = jb.seg + (size_t)job * SEG_MAX + (vjob % jb.smax);
     JobMeta *m = &jb.meta[job];
-    if (st.hdr->fallback > 0) return;                                             // k_fill_v2 stands in (after a stall)
+    if (st.hdr->fallback > 0 && jb.v2_follows) return;                            // k_fill_v2 stands in (after a stall)
     if (!m->active || m->L <= 0 || !m->ok || m->wide || !sd->active) return;
     // The segment is a DP of its own on the rows [xb, xe) of the job: x below counts from xb, and everything indexed by DP
     // row is addressed from there.  Its first row starts free (PW:265) whether it is the row's first base or not; its last
@@ -1807,7 +1811,7 @@ __global__ __launch_bounds__(256) void k_seg_check(DState st, JobBufs jb)
     __shared__ int s_min[4], s_max[4], s_bad;
     const int job = blockIdx.x, s = blockIdx.y + 1, tid = threadIdx.x;
     JobMeta *m = &jb.meta[job];
-    if (!m->active || m->L <= 0 || !m->ok || m->wide || m->abort || st.hdr->fallback > 0) return;
+    if (!m->active || m->L <= 0 || !m->ok || m->wide || m->abort || (st.hdr->fallback > 0 && jb.v2_follows)) return;
     if (s >= m->nseg) return;
     const SegDesc *sd = jb.seg + (size_t)job * SEG_MAX + s;
     const int xr = sd->xown - 1;                                                   // the row both segments have
@@ -3101,6 +3105,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
                 stopped = true;
                 continue;
             }
+            if (m->wide && !jb.f64_follows) { stopped = true; continue; }         // (its batch came without k_fill64: the next ones bring it)
             if (m->abort) {
                 // k_fill_v3 gave this job up (time-out): it is realigned again, by k_fill_v2, as are the next batches
                 if (threadIdx.x == 0) {
@@ -3159,7 +3164,8 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
         h->next_row += adv;
         h->ahead = adv >= 64 ? 0ull : dm >> adv;
         h->rows_ahead += (unsigned long long)ahead_n;
-        if (h->fallback > 0) h->fallback -= 1;
+        if (h->fallback > 0 && jb.v2_follows) h->fallback -= 1;
+        if (h->need64 > 0 && jb.f64_follows) h->need64 -= 1;
         if (live_all > 0) h->batches += 1;
         h->rows_committed += (unsigned long long)live_done;
         h->rows_recomputed += (unsigned long long)(live_all - live_done);
@@ -3275,6 +3281,7 @@ struct pwr_ctx {
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int spec_len = 6;                     // percent a speculative row may be longer than the first row of its batch (option "spec_len")
     int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP; cross-check and fallback)
+    int seen_fallback = 0, seen_need64 = 0;   // Hdr::fallback / need64 as the host last saw them: the batches it enqueues bring k_fill_v2 / k_fill64 along
     unsigned trace_epoch = 0;             // k_trace_par launch counter (22 bits)
     unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
     int wp_waves = 5;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane (5: measured best with segments side by side)
@@ -3700,6 +3707,7 @@ static int launch_fill(pwr_ctx *c, int njobs)
         c->jb.tagbase = c->fill_epoch << 17;
         c->jb.njobs_launched = njobs;
         c->jb.stall_test = c->stall_test > 0 ? 1 : 0;
+        c->jb.v2_follows = (c->seen_fallback > 0 && c->wp_waves != 17) ? 1 : 0;
         if (c->stall_test > 0) c->stall_test -= 1;
         const int nv = njobs * c->jb.smax;                                 // one slot per (job, segment)
         const dim3 grid(8, c->wp_waves, (nv + 7) / 8);
@@ -3726,7 +3734,8 @@ static int launch_fill(pwr_ctx *c, int njobs)
     // k_fill_v2: the fill of its own right (option fill = 3), or the stand-in behind k_fill_v3 that only runs while
     // Hdr::fallback > 0, i.e. after a k_fill_v3 job gave up waiting for a neighbour work-group
     c->jb.gate_v2 = c->fill_mode == 4 ? 1 : 0;
-    if (c->fill_mode == 3 || (c->fill_mode == 4 && c->wp_waves != 17)) {
+    if (c->fill_mode == 3) c->jb.v2_follows = 1;
+    if (c->fill_mode == 3 || (c->fill_mode == 4 && c->jb.v2_follows)) {
         if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v2<5, 4>), dim3(njobs), dim3(5 * 64), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v2<8, 3>), dim3(njobs), dim3(8 * 64), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v2<4, 6>), dim3(njobs), dim3(4 * 64), 0, c->stream, c->st, c->jb);
@@ -3793,10 +3802,11 @@ static int enqueue_batch(pwr_ctx *c)
     const int n = c->window;
     int rc;
     c->jb.gather_tag = ++c->gather_tag;
+    c->jb.f64_follows = (c->seen_need64 > 0 || c->force64) ? 1 : 0;
     hipLaunchKernelGGL(k_gather_a, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids);
     hipLaunchKernelGGL(k_gather_c, dim3(n, GATHER_G + 1), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
     if ((rc = launch_fill(c, n))) return rc;
-    hipLaunchKernelGGL(k_fill64, dim3(n), dim3(F64_NT), 0, c->stream, c->st, c->jb);       // jobs the gather flagged wide (none, normally)
+    if (c->jb.f64_follows) hipLaunchKernelGGL(k_fill64, dim3(n), dim3(F64_NT), 0, c->stream, c->st, c->jb);   // jobs the gather flagged wide
     if (c->par_trace) {
         if (++c->trace_epoch >= (1u << 14)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * c->jb.trk * 8, c->stream)); c->trace_epoch = 1; }
         c->jb.trace_tag = c->trace_epoch;
@@ -3858,6 +3868,7 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
         HIPC(hipEventSynchronize(c->ring_ev[slot]));
         const Hdr h = ring[slot];
         ++looked;
+        c->seen_fallback = h.fallback; c->seen_need64 = h.need64;
         if (h.status) { (void)hipStreamSynchronize(c->stream); return h.status; }
         if (h.need_grow) {
             // the batches queued behind this one do nothing while the flag is up
@@ -3868,12 +3879,13 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
             return realign_range(c, h.next_row, kend - h.next_row, true);
         }
         if (h.next_row >= kend) break;
-        if (h.ncommitted == 0 && most < 2LL * n + 64) ++most;                   // ... except one whose first job stalled (it is repeated by k_fill_v2)
+        if (h.ncommitted == 0 && most < 2LL * n + 64) ++most;                   // ... except one whose first job stalled, failed its segment check, or came without the kernel it needed
     }
     HIPC(hipStreamSynchronize(c->stream));                                     // the no-op batches behind the last real one
     Hdr h;
     if ((rc = read_hdr(c, &h))) return rc;
     c->batch_ema = h.ema;
+    c->seen_fallback = h.fallback; c->seen_need64 = h.need64;
     stats_from_hdr(c, h);
     return h.status;
 }
