@@ -60,7 +60,8 @@ struct Hdr {                       // lives in device memory, one per context
     int speclen;                   // a speculative row may be this many percent longer than the batch's first row
     unsigned long long ahead;      // bit b: row next_row + b was committed ahead of an earlier, stale row it commutes with (its band
                                    // interval is disjoint from that row's), so the batches to come leave it out
-    int noseg_row;                 // this row's segmented fill failed its check: its next fill runs in one piece (-1: none)
+    int noseg_row;                 // this row's segmented fill failed its check (-1: none) ...
+    int noseg_level, pad2;         // ... once: its next fill warms up twice as long; twice: it runs in one piece
     int need64;                    // > 0: a job needed the 64-bit fill lately; the host launches k_fill64 with the batches while this counts down
     unsigned long long dbg[32];    // phase timers of commit and trace (10 ns ticks), only written by builds with -DPWR_DIAG
 };
@@ -382,8 +383,9 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, c
 }
 
 // The plan of a job's fill (one work-group): how many segments, where each starts to warm up, the cells it computes.
-// Own parts start at multiples of 64 rows (the fill works in blocks of 64 rows and stores its record per 16); a warm-up
-// starts at the last multiple of 64 whose band lies at least warm_cols columns left of the own part's first band.
+// Own parts start at multiples of 64 rows; a warm-up starts at the last multiple of 16 (the fill stores its record per 16 rows)
+// whose band lies at least warm_cols columns left of the own part's first band.  A row whose check failed is planned again
+// with twice the warm-up, and in one piece if that fails too (Hdr::noseg_row / noseg_level).
 __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
 {
     __shared__ int s_x[SEG_MAX + 1], s_xb[SEG_MAX], s_S;
@@ -394,27 +396,30 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
     if (!m->active || m->L <= 0) { if (tid < SEG_MAX) sg[tid].active = 0; return; }
     const int L = m->L, W = m->W, B = st.B, H = st.H;
     const int *way = jb.way + (size_t)job * jb.Lmax;
+    __shared__ int s_warm;
     if (tid == 0) {
         int S = 1;
-        if (jb.seg_rows > 0 && st.hdr->noseg_row != m->k) S = (L + jb.seg_rows / 2) / jb.seg_rows;
+        const int level = st.hdr->noseg_row == m->k ? st.hdr->noseg_level : 0;     // how often this row's check has failed
+        if (jb.seg_rows > 0 && level < 2) S = (L + jb.seg_rows / 2) / jb.seg_rows;
         S = max(1, min(S, min(jb.smax, L / 128)));
         s_S = S;
+        s_warm = level == 1 ? 2 * jb.warm_cols : jb.warm_cols;
         m->nseg = S; m->segfail = 0;
     }
     if (tid < SEG_MAX) s_cells[tid] = 0;
     __syncthreads();
-    const int S = s_S;
+    const int S = s_S, warm = s_warm;
     if (tid <= S) s_x[tid] = tid == S ? L : (int)(((long long)L * tid / S) & ~63ll);
     __syncthreads();
     if (tid < S) {
         int xb = 0;
         if (tid > 0) {
-            // largest multiple of 64 below x_s whose row sits at least warm_cols columns left of row x_s (Way[] is increasing)
-            const int xs = s_x[tid], lim = way[xs] - jb.warm_cols;
-            int a = 0, b = xs / 64 - 1;                       // candidates 64 * [0, b]
+            // largest multiple of 16 below x_s whose row sits at least warm columns left of row x_s (Way[] is increasing)
+            const int xs = s_x[tid], lim = way[xs] - warm;
+            int a = 0, b = xs / 16 - 1;                       // candidates 16 * [0, b]
             if (way[0] > lim) b = -1;
-            while (a < b) { const int mid = (a + b + 1) >> 1; if (way[64 * mid] <= lim) a = mid; else b = mid - 1; }
-            xb = b < 0 ? 0 : 64 * a;
+            while (a < b) { const int mid = (a + b + 1) >> 1; if (way[16 * mid] <= lim) a = mid; else b = mid - 1; }
+            xb = b < 0 ? 0 : 16 * a;
         }
         s_xb[tid] = xb;
     }
@@ -3118,7 +3123,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
             if (m->segfail) {
                 // a segment of its fill had not forgotten its start when its own rows began (k_seg_check): the row is
                 // realigned again, its fill in one piece
-                if (threadIdx.x == 0) { h->seg_fails += 1; h->noseg_row = m->k; }
+                if (threadIdx.x == 0) { h->seg_fails += 1; h->noseg_level = h->noseg_row == m->k ? h->noseg_level + 1 : 1; h->noseg_row = m->k; }
                 stopped = true;
                 continue;
             }
@@ -3146,7 +3151,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
                 continue;
             }
             commit_job(st, jb, j, sh, s_i, &evs);
-            if (threadIdx.x == 0 && h->noseg_row == m->k) h->noseg_row = -1;
+            if (threadIdx.x == 0 && h->noseg_row == m->k) { h->noseg_row = -1; h->noseg_level = 0; }
             live_done += 1;
             if (nskip > 0) ahead_n += 1;
             if (m->wide && threadIdx.x == 0) h->rows_wide += 1;
@@ -3464,7 +3469,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
     jb.seg_rows = c->fill_mode == 4 ? c->seg_rows : 0;
     jb.warm_cols = (int)std::min<long long>((long long)c->B * c->warm_pct / 100 + 2, 1 << 20);
-    jb.gstride = jb.Lmax + jb.smax * (jb.warm_cols + 64);
+    jb.gstride = jb.Lmax + jb.smax * (2 * jb.warm_cols + 64);          // (a row whose check failed warms up twice as long)
     if ((rc = dmalloc(c, &jb.seg, (size_t)njobs * SEG_MAX))) return rc;
     if (hipMemsetAsync(jb.seg, 0, sizeof(SegDesc) * (size_t)njobs * SEG_MAX, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     if ((rc = dmalloc(c, &jb.chk, (size_t)njobs * (SEG_MAX + 1) * 2 * NC))) return rc;
@@ -3879,7 +3884,7 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
             return realign_range(c, h.next_row, kend - h.next_row, true);
         }
         if (h.next_row >= kend) break;
-        if (h.ncommitted == 0 && most < 2LL * n + 64) ++most;                   // ... except one whose first job stalled, failed its segment check, or came without the kernel it needed
+        if (h.ncommitted == 0 && most < 4LL * n + 256) ++most;                  // ... except one whose first job stalled, failed its segment check, or came without the kernel it needed
     }
     HIPC(hipStreamSynchronize(c->stream));                                     // the no-op batches behind the last real one
     Hdr h;

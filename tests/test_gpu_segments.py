@@ -54,7 +54,7 @@ def test_failed_segment_check_repeats_the_row_in_one_piece(oracle):
 
 def test_cells_computed_count_the_warm_up_rows(oracle):
     """pwr_stats.cells_computed (the numerator of bench.py's roofline figure) against the plan restated here: segment s of
-    a row owns the rows [x_s, x_{s+1}), x_s = floor(L s / S) rounded down to 64, and warms up from the last multiple of 64
+    a row owns the rows [x_s, x_{s+1}), x_s = floor(L s / S) rounded down to 64, and warms up from the last multiple of 16
     whose base lies at least warm_cols columns left of base x_s; every row of it costs min(B, W - anf) cells."""
     from repeatresolver_amd.realigner import PWReAligner
     rows = split_rows(golden_input("toy_b_b1000"))
@@ -80,7 +80,7 @@ def test_cells_computed_count_the_warm_up_rows(oracle):
         for s in range(S):
             xb = 0
             if s > 0:
-                cand = [c for c in range(0, xs[s], 64) if way[c] <= way[xs[s]] - warm_cols]
+                cand = [c for c in range(0, xs[s], 16) if way[c] <= way[xs[s]] - warm_cols]
                 xb = cand[-1] if cand else 0
             exp_cells += int(cells[xb:xs[s + 1]].sum())
         if S > 1:
