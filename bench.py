@@ -117,6 +117,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dev = 0 if args.one_device else local_rank
     if world > 1:
+        ndev = torch.cuda.device_count()
+        if not args.one_device and ndev < world:
+            raise SystemExit(f"bench.py --gpus {world}: one process per GPU needs {world} visible devices, this node shows {ndev} "
+                             "(a rehearsal on fewer devices: --one-device --backend gloo)")
         torch.cuda.set_device(dev)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
@@ -165,7 +169,8 @@ def main():
             owner[p] = r
             load[r] += cost[p]
         units = [(f"section {p} columns [{bounds[p]},{bounds[p + 1]})", secs[p]) for p in range(len(secs)) if owner[p] == rank]
-        note(f"sections {bounds} dealt as {owner}")
+        owned = [[p for p in range(len(secs)) if owner[p] == r] for r in range(world)]
+        note(f"sections {bounds} dealt as {owner}: " + ", ".join(f"rank {r} {owned[r] or 'IDLE'} ({load[r]} bases)" for r in range(world)))
     ctxs = []
     score0 = 0
     for _, urows in units:
@@ -223,6 +228,10 @@ def main():
             per_rank = [{"rank": r, "seconds": float(ts[r].item()), "cells": float(css[r].item())} for r in range(world)]
             tmax = max(p["seconds"] for p in per_rank)
             csum = sum(p["cells"] for p in per_rank)
+            for p_ in per_rank:                    # a scaling curve must explain itself: 6 sections on 8 ranks leave 2 ranks idle
+                p_["sections"] = owned[p_["rank"]]
+                p_["bases"] = load[p_["rank"]]
+                p_["idle_s"] = tmax - p_["seconds"] if owned[p_["rank"]] else tmax
         if rank != 0:
             return
         fill_s = st["fill_ms"] / 1e3
@@ -270,8 +279,11 @@ def main():
                        "generate_s": round(gen_s, 1), "input": args.input, "initial_aligner": ia_info, "complete": bool(final)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
+                         "frac_useful_cells": (achieved / HBM_PEAK_GBS) * (st["cells_reference"] / st["cells_computed"]) if st["cells_computed"] else None,
                          "traffic": traffic,
                          "traffic_note": (f"HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of `{traffic_cmd}` (profiles/bench_traffic.json)"
+                                          + ("" if traffic_cmd and traffic_cmd.strip() == f"bench.py --steps {args.steps} --warmup {args.warmup}" and not args.opt and args.window is None
+                                             else "; NOT this run's command: a committed measurement of another invocation")
                                           if traffic is not None else "no PMC pass of this command is committed"),
                          "algorithmic_bytes_per_launch": BYTES_PER_CELL * st["cells_computed"] / launches,
                          "kernel": FILL_KERNELS.get(ctxs[0].get_option("fill") if ctxs else 4, "k_fill"),
@@ -279,8 +291,9 @@ def main():
                          "avg_launch_ms": st["fill_ms"] / timed,
                          "cells_per_launch": st["cells_computed"] / launches,
                          "cells_reference": st["cells_reference"], "cells_computed": st["cells_computed"],
-                         "note": "achieved = DP cells computed by the fill kernel (speculative ones included) x 4 B / sum of HIP-event "
-                                 "durations of its launches on the context's stream (rank 0's contexts)"},
+                         "note": "achieved = DP cells computed by the fill kernel (the warm-up rows of its segments and speculative fills that were "
+                                 "thrown away included: config.useful_frac of them are cells the reference fills) x 4 B / sum of HIP-event durations of "
+                                 "its launches (with its segment check) on the context's stream (rank 0's contexts); frac_useful_cells counts only the reference's cells"},
         }
         if per_rank is not None:
             out["per_rank"] = per_rank

@@ -60,6 +60,8 @@ def realign_sections(sections, bandwidth=1000, max_rounds=-1, worker=None, devic
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     use_cuda = dist.is_initialized() and dist.get_backend() == "nccl"
+    if use_cuda and torch.cuda.device_count() < 1:
+        raise RuntimeError("process group `nccl` (RCCL) but no HIP device is visible to this rank: one process per GPU")
     if device is None:
         device = torch.cuda.current_device() if (use_cuda or (not dist.is_initialized() and torch.cuda.is_available())) else 0
     worker = worker or gpu_realign_section

@@ -94,3 +94,45 @@ def test_restatement_against_literal_transcription(mco):
     exp = literal_maxcorrs(rows, 12, lambda *a: mco.mco_significance(*a))
     assert np.array_equal(got, exp)
     assert (got > 3).sum() > 10 and (got == 0).sum() > 10            # linked variants stand out, most variations do not exist
+
+
+def test_significance_branches_against_exact_rationals(mco):
+    """PositiveSignificance saturates in two steps (Z > 99 -> 99, MC:417; Z > 98 -> 98 + F, MC:432): a rounding difference in
+    the tail right at those thresholds would flip a branch and move the value by up to one.  The tail of the restatement is
+    compared here with the EXACT tail (Python integers: sum of C(n1, i) C(n2, t - i) over i > k, over C(n1 + n2, t)) for the
+    counts whose -log10 lies nearest to 98 and 99 -- the branch taken must be the exact one, the value within 1e-9."""
+    from math import comb
+    from decimal import Decimal, getcontext
+    getcontext().prec = 60
+    rng = np.random.default_rng(7)
+    checked = near = 0
+    for _ in range(60):
+        n1 = int(rng.integers(150, 900)); n2 = int(rng.integers(150, 900)); t = int(rng.integers(120, n1 + n2 - 50))
+        den = comb(n1 + n2, t)
+        hi = min(n1, t)
+        # exact upper tails P(X > k) for all k, from the top down
+        tail = 0
+        exact = {}
+        for i in range(hi, -1, -1):
+            exact[i] = tail                                          # P(X > i) * den
+            tail += comb(n1, i) * comb(n2, t - i) if 0 <= t - i <= n2 else 0
+        for k in range(hi):
+            if exact[k] == 0:
+                continue
+            z_exact = -(Decimal(exact[k]) / Decimal(den)).log10()
+            if not (Decimal(96) < z_exact < Decimal(101)):
+                continue
+            q = mco.mco_hyper_Q(k, n1, n2, t)
+            z = -np.log10(q)
+            assert abs(Decimal(float(z)) - z_exact) < Decimal("1e-9"), (k, n1, n2, t)
+            assert (z > 99) == (z_exact > 99) and (z > 98.0) == (z_exact > 98), (k, n1, n2, t, float(z), z_exact)
+            checked += 1
+            near += abs(z_exact - 98) < Decimal("0.5") or abs(z_exact - 99) < Decimal("0.5")
+            # the whole function on counts that produce this tail: schnitt - 1 = k, gr2 = n1, cov - gr2 = n2, gr1 = t
+            zz = mco.mco_significance(k + 1, n1 + n2, t, n1, t + 5, n1 + 7)
+            if z_exact > 98:
+                f = 2.0 * (k + 1) / (2.0 * (k + 1) + (t + 5 - k - 1) + (n1 + 7 - k - 1))
+                assert zz == pytest.approx(98.0 + f, abs=1e-12)
+            else:
+                assert zz == pytest.approx(float(z_exact), abs=1e-9)
+    assert checked > 100 and near > 10
