@@ -1381,6 +1381,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
                     for (int i = 0; i < C; ++i) sgr[i] = srow0[i];
                 }
                 int af_done = a_prev;
+                int g_af = 0, g_be = 0, g_cs = 0, g_cp = -1;                      // (see below: the current group's rows, lane = row of the group)
                 DG_INC(dg_runs, 1)
                 while (true) {
                     const int r_beg = x & 15, g0 = x - r_beg, r0 = g0 & 63;
@@ -1423,14 +1424,24 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
                     }
                     unsigned long long *const gq0 = gmy + 2 * (size_t)g0;
                     const unsigned long long *const ringM = &rM[lw][g0 & (RB - 1)], *const ringP = &rP[lw][g0 & (RB - 1)];   // the group's 16 consecutive slots
-                    auto group_row = [&](const int r, auto cls_) __attribute__((always_inline)) {
+                    // the group's rows in lanes 0..16 of their own registers (lane r: row g0 + r; lane 16: the first row of the next
+                    // group, for the look-ahead of the substitution column): every v_readlane below then has a constant lane
+                    if (g0 != g_cp) {
+                        const int src = 4 * min(r0 + lane, 63);
+                        g_af = __builtin_amdgcn_ds_bpermute(src, dcaf);
+                        g_be = __builtin_amdgcn_ds_bpermute(src, dcb);
+                        g_cs = __builtin_amdgcn_ds_bpermute(src, (int)dcs);
+                        g_cp = g0;
+                    }
+                    auto group_row = [&](const int r, auto cls_, auto bits_) __attribute__((always_inline)) {
                         constexpr int CLS = decltype(cls_)::value;                 // 0 INTERIOR, 1 RIGHT, 2 LEFT, 3 run-time flags
+                        constexpr bool BITS = decltype(bits_)::value;              // false: a row of the warm-up, whose record nobody keeps
                         const int xr = g0 + r;
                         bool bP = CLS <= 1 || CLS == 4, bM = CLS <= 1 || CLS == 4;
                         if (CLS == 3) { bP = (nPm >> r) & 1u; bM = (kMm >> r) & 1u; }
                         int af = 0, bend = 0;
-                        if (CLS >= 2) af = __builtin_amdgcn_readlane(dcaf, r0 + r);
-                        if (CLS == 1 || CLS == 3 || CLS == 4) bend = __builtin_amdgcn_readlane(dcb, r0 + r);
+                        if (CLS >= 2) af = __builtin_amdgcn_readlane(g_af, r);
+                        if (CLS == 1 || CLS == 3 || CLS == 4) bend = __builtin_amdgcn_readlane(g_be, r);
                         const int Mleft_v = bM ? (int)mlast_v : (int)PWR_INF;
                         const int pm1_0 = __builtin_amdgcn_update_dpp(Mleft_v, (int)Mprev[C - 1], DPP_WAVE_SHR1, 0xF, 0xF, false);
                         int tg[C];
@@ -1440,7 +1451,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
                             const int pm1 = i ? (int)Mprev[i > 0 ? i - 1 : 0] : pm1_0;
                             const int d = pm1 + sgr[i];
                             const int u = (int)Mprev[i] + ug[i];
-                            accC[i] = acc_push(accC[i], __builtin_amdgcn_sicmp(d, u, ICMP_SLE));
+                            if (BITS) accC[i] = acc_push(accC[i], __builtin_amdgcn_sicmp(d, u, ICMP_SLE));
                             const int t3 = min(min(d, u), ig[i]);
                             bool inb = true;
                             if (CLS == 1 || CLS == 4) inb = ycol[i] < bend;
@@ -1462,7 +1473,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
 #define V4_FENCE() __builtin_amdgcn_sched_barrier(0)
                         int incl = run;
                         V4_SCAN_STEP(DPP_ROW_SHR(1), 0xF) V4_FENCE();
-                        const int soff = __builtin_amdgcn_readlane((int)dcs, min(r0 + r + 1, 63));    // (past the block's end: reloaded below)
+                        const int soff = __builtin_amdgcn_readlane(g_cs, r + 1);                      // (past the block's end: reloaded below)
                         V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(2), 0xF) V4_FENCE();
                         const int *const srow = (const int *)(stab + soff);
                         V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(4), 0xF) V4_FENCE();
@@ -1498,7 +1509,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
                         int p = min(__builtin_amdgcn_update_dpp(pq, incl, DPP_WAVE_SHR1, 0xF, 0xF, false), pq);
 #pragma unroll
                         for (int i = 0; i < C; ++i) {
-                            accA[i] = acc_push(accA[i], __builtin_amdgcn_sicmp(tg[i], p, ICMP_SGE));
+                            if (BITS) accA[i] = acc_push(accA[i], __builtin_amdgcn_sicmp(tg[i], p, ICMP_SGE));
                             p = min(p, tg[i]);
                             Mprev[i] = min((unsigned)(gg[i] + p), PWR_INF);
                         }
@@ -1518,33 +1529,51 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
                     // So: whole INTERIOR groups as 16 rows of straight-line code; everything else in blocks of 4 rows per role,
                     // aligned to 4 -- the band's leading strip, which sets the pace of the whole pipeline, is LEFT for only ~28
                     // rows at a time and would otherwise spend most of them in the one-row loop --, and that loop for the rest.
-                    if (cls == 0 && r_beg == 0 && r_e == 16) {
+                    using WithBits = std::integral_constant<bool, true>;
+                    using NoBits = std::integral_constant<bool, false>;
+                    const bool warmup = (x >> 4) < g_own;                          // (the group lies in the warm-up: its record is not kept)
+                    if (warmup && r_beg == 0 && r_e == 16 && cls != 3) {
+                        // whole groups of the warm-up -- seven rows in ten of a segment --, one role: the same straight-line code without
+                        // the two compare-and-shift pairs per cell that make the record
+                        if (cls == 0) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, PWR_INTERIOR_CLS>{});
+                            for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, PWR_INTERIOR_CLS>{}, NoBits{});
+                            DG_INC(dg_int, 16)
+                            DG_ADD2(dg_cyc_int)
+                        } else if (cls == 1) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 1>{}, NoBits{});
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 2>{}, NoBits{});
+                        }
+                    } else if (cls == 0 && r_beg == 0 && r_e == 16) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, PWR_INTERIOR_CLS>{}, WithBits{});
                         DG_INC(dg_int, 16)
                         DG_ADD2(dg_cyc_int)
                     } else if (cls == 1 && r_beg == 0 && r_e == 16) {
                         // (the band's last strip: its wave has just taken it over and the next strip's wave is waiting for it --
                         // this is the pipeline's critical path, so whole groups get straight-line code here too)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 1>{});
+                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 1>{}, WithBits{});
                     } else if (cls == 3 && r_beg == 0 && r_e == 16) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 3>{});
+                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 3>{}, WithBits{});
                     } else if (cls == 2 && r_beg == 0 && r_e == 16) {
                         // (the band's first strip: with every follower close behind its neighbour, its rows set the pace)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 2>{});
+                        for (int r = 0; r < 16; ++r) group_row(r, std::integral_constant<int, 2>{}, WithBits{});
                     } else {
                         int r = r_beg;
-                        for (; r < r_end && (r & 3) && !dead; ++r) group_row(r, std::integral_constant<int, 3>{});
-#define V4_BLOCKS(K) for (; r + 4 <= r_end && !dead; r += 4) { group_row(r, std::integral_constant<int, K>{}); group_row(r + 1, std::integral_constant<int, K>{}); \
-                                                               group_row(r + 2, std::integral_constant<int, K>{}); group_row(r + 3, std::integral_constant<int, K>{}); }
+                        for (; r < r_end && (r & 3) && !dead; ++r) group_row(r, std::integral_constant<int, 3>{}, WithBits{});
+#define V4_BLOCKS(K) for (; r + 4 <= r_end && !dead; r += 4) { group_row(r, std::integral_constant<int, K>{}, WithBits{}); group_row(r + 1, std::integral_constant<int, K>{}, WithBits{}); \
+                                                               group_row(r + 2, std::integral_constant<int, K>{}, WithBits{}); group_row(r + 3, std::integral_constant<int, K>{}, WithBits{}); }
                         if (cls == 0) V4_BLOCKS(0)
                         else if (cls == 1) V4_BLOCKS(1)
                         else if (cls == 2) V4_BLOCKS(2)
 #undef V4_BLOCKS
-                        for (; r < r_end && !dead; ++r) group_row(r, std::integral_constant<int, 3>{});
+                        for (; r < r_end && !dead; ++r) group_row(r, std::integral_constant<int, 3>{}, WithBits{});
                         r_end = r;
                     }
                     if (!(cls == 0 && r_beg == 0 && r_e == 16)) { DG_INC(dg_gen16, r_end - r_beg) DG_ADD2(dg_cyc_gen16) }
@@ -1573,6 +1602,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
                         V4_EARLY_MASKS()
                         dcaf = (int)(dca & 0xffffffu); dcb = min(dcaf + B, W);
                         dcs = min(dca >> 24, 3u) * (unsigned)(MS * 4);
+                        g_cp = -1;
                         const int *const srow0 = (const int *)(stab + __builtin_amdgcn_readlane((int)dcs, 0));
 #pragma unroll
                         for (int i = 0; i < C; ++i) sgr[i] = srow0[i];
