@@ -1423,6 +1423,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
                         }
                     }
                     unsigned long long *const gq0 = gmy + 2 * (size_t)g0;
+                    const unsigned tag_g0 = tagbase | (unsigned)g0;                 // (the rows' tags are this + r + 1)
                     const unsigned long long *const ringM = &rM[lw][g0 & (RB - 1)], *const ringP = &rP[lw][g0 & (RB - 1)];   // the group's 16 consecutive slots
                     // the group's rows in lanes 0..16 of their own registers (lane r: row g0 + r; lane 16: the first row of the next
                     // group, for the look-ahead of the substitution column): every v_readlane below then has a constant lane
@@ -1436,7 +1437,6 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
                     auto group_row = [&](const int r, auto cls_, auto bits_) __attribute__((always_inline)) {
                         constexpr int CLS = decltype(cls_)::value;                 // 0 INTERIOR, 1 RIGHT, 2 LEFT, 3 run-time flags
                         constexpr bool BITS = decltype(bits_)::value;              // false: a row of the warm-up, whose record nobody keeps
-                        const int xr = g0 + r;
                         bool bP = CLS <= 1 || CLS == 4, bM = CLS <= 1 || CLS == 4;
                         if (CLS == 3) { bP = (nPm >> r) & 1u; bM = (kMm >> r) & 1u; }
                         int af = 0, bend = 0;
@@ -1480,7 +1480,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
 #pragma unroll
                         for (int i = 0; i < C; ++i) sgr[i] = srow[i];
                         V4_FENCE(); V4_SCAN_STEP(DPP_ROW_SHR(8), 0xF) V4_FENCE();
-                        const unsigned tagx = tagbase | (unsigned)(xr + 1);
+                        const unsigned tagx = tag_g0 + (unsigned)(r + 1);            // = tagbase | (xr + 1): g0 is a multiple of 16
                         V4_FENCE(); V4_SCAN_STEP(DPP_ROW_BCAST15, 0xA) V4_FENCE();
                         V4_FENCE(); V4_SCAN_STEP(DPP_ROW_BCAST31, 0xC) V4_FENCE();
 #undef V4_SCAN_STEP
@@ -1515,11 +1515,20 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
                         }
                         mlast_v = (unsigned)fM;
                         if (lane == 63) {
-                            GST2(gq0 + 2 * r, P_end_v, tagx);
                             if (WG1) {
+                                GST2(gq0 + 2 * r, P_end_v, tagx);
                                 LST(rP[wr][(g0 + r) & (RB - 1)], ((unsigned long long)tagx << 32) | (unsigned)P_end_v);
                                 LST(rM[wr][(g0 + r) & (RB - 1)], ((unsigned long long)tagx << 32) | (unsigned)Mprev[C - 1]);   // P before M: M's tag vouches for both
-                            } else GST2(gq0 + 2 * r + 1, Mprev[C - 1], tagx);
+                            } else {
+                                // both words in one 16-byte store: each carries its own tag, so it does not matter in which order
+                                // (or in how many pieces) a reader comes to see them
+                                typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+                                v4u_ w4_; w4_.x = (unsigned)P_end_v; w4_.y = tagx; w4_.z = Mprev[C - 1]; w4_.w = tagx;
+                                // (sc1 as the agent-scope atomic stores have it: the words must be seen by the other work-groups)
+                                // (and the wait states a store of more than 64 bits needs before a VALU may overwrite its data
+                                // registers: the compiler inserts them for its own stores, not behind inline assembly)
+                                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(gq0 + 2 * r), "v"(w4_) : "memory");
+                            }
                         }
                     };
                     int r_end = r_e;
