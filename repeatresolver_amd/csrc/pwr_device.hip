@@ -2521,6 +2521,31 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
         int e = 0;
         while (x >= x_lo && !e) {
             x = UNI(x); y = UNI(y); gcur = UNI(gcur); yb = UNI(yb); gpre = UNI(gpre); ybpre = UNI(ybpre); cnt = UNI(cnt);
+            // ---- the common case, straight: rows of the current 16-row group whose step lies in the 64-cell part of the window
+            //      that holds the current column
+            while ((x >> 4) == gcur && x >= x_lo) {
+                if (check_merge && x >= xrec_lo && __builtin_amdgcn_readlane(yireg, x & 63) == y) { merged = true; break; }
+                const int af = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+                const int ycf = min(y, af + min(B, W - af) - 1);
+                if (y < af || ycf < yb || ycf > yb + 255) break;
+                const int q0 = (ycf - yb) >> 6, shf = 15 - (x & 15);
+                const uint32_t wq = q0 == 0 ? win[0] : q0 == 1 ? win[1] : q0 == 2 ? win[2] : win[3];
+                const int cy = yb + 64 * q0 + lane;
+                const unsigned long long mk = __ballot(cy <= ycf && cy >= af && !((wq >> shf) & 1u));
+                if (!mk) break;
+                const int t = 63 - __builtin_clzll(mk);
+                const int yy = yb + 64 * q0 + t;
+                const int cb = (int)((__ballot((wq >> (16 + shf)) & 1u) >> t) & 1ull);
+                const int nv = (yy << 1) | (cb ^ 1);                               // PW:1394 (c) / PW:1404 (d)
+                if (x >= xrec_lo) cnt -= __builtin_amdgcn_readlane(ncreg, x & 63) & 1;
+                cnt += nv & 1;
+                ncreg = (lane == (x & 63)) ? nv : ncreg;
+                yireg = (lane == (x & 63)) ? y : yireg;
+                y = yy - cb;                                                       // diag: column to the left, up: stay
+                --x;
+                if (x >= 0 && y < 0) { e = 3; break; }
+            }
+            if (merged || e || x < x_lo) break;
             if (check_merge && x >= xrec_lo && __builtin_amdgcn_readlane(yireg, x & 63) == y) { merged = true; break; }
             const int a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
             const int Bx = min(B, W - a);
@@ -3115,7 +3140,7 @@ __device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsig
 // always invalidated while the MSA is still moving, so speculate just past the running mean of rows committed per batch --
 // and never let a speculative row make the batch longer than its first row, the only one that is certain to commit (a fill
 // takes time proportional to the row's length).
-__global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs jb, int njobs, const int *rowids)
+__global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs jb, int njobs, const int *rowids, Hdr *host_copy)
 {
     __shared__ unsigned sh[COMMIT_NT / 64];
     __shared__ int s_i[12];
@@ -3126,7 +3151,11 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
 #endif
     if (threadIdx.x == 0) { h->ncommitted = 0; h->stop = 0; }
     __syncthreads();
-    if (h->status != 0 || h->need_grow) return;
+    if (h->status != 0 || h->need_grow) {
+        // (the host looks at its copy of the header after every batch: pinned host memory, written from here)
+        if (host_copy && threadIdx.x < sizeof(Hdr) / 4) reinterpret_cast<volatile int *>(host_copy)[threadIdx.x] = reinterpret_cast<const int *>(h)[threadIdx.x];
+        return;
+    }
     // Jobs in row order.  A stale job (its inputs were changed by a commit since the gather) is left for the next batch --
     // and a later job may still commit AHEAD of it when the two commute: their band intervals [lo, hi] (every column either
     // DP reads or either commit writes) are disjoint, with a margin for the column a commit may open at its interval's edge.
@@ -3230,6 +3259,10 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
         h->dbg[10] += __builtin_amdgcn_s_memrealtime() - ph_chain0; h->dbg[11] += 1;
 #endif
     }
+    // the header as it stands after this batch, for the host (pinned memory: no copy command behind every batch)
+    __threadfence();
+    __syncthreads();
+    if (host_copy && threadIdx.x < sizeof(Hdr) / 4) reinterpret_cast<volatile int *>(host_copy)[threadIdx.x] = reinterpret_cast<const int *>(h)[threadIdx.x];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3841,7 +3874,7 @@ static int check_status(pwr_ctx *c)
 // One speculative batch, enqueued without waiting: the rows rowids[next_row ...] (Hdr, at most `window` of them) are
 // gathered from the committed state, filled and traced side by side, then committed in row order by one work-group that stops
 // at the first row whose inputs an earlier commit of this batch has changed, moves next_row on and sizes the next batch.
-static int enqueue_batch(pwr_ctx *c)
+static int enqueue_batch(pwr_ctx *c, Hdr *host_copy)
 {
     const int n = c->window;
     int rc;
@@ -3858,7 +3891,7 @@ static int enqueue_batch(pwr_ctx *c)
         else hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
     }
     else hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
-    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n, c->d_rowids);
+    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n, c->d_rowids, host_copy);
     HIPC(hipGetLastError());
     return PWR_OK;
 }
@@ -3901,9 +3934,8 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
     long long most = n;                                                        // every batch with rows left commits at least one ...
     while (true) {
         while (issued < most && issued - looked < PWR_INFLIGHT) {
-            if ((rc = enqueue_batch(c))) return rc;
             const int slot = (int)(issued % PWR_INFLIGHT);
-            HIPC(hipMemcpyAsync(&ring[slot], c->st.hdr, sizeof(Hdr), hipMemcpyDeviceToHost, c->stream));
+            if ((rc = enqueue_batch(c, &ring[slot]))) return rc;               // (its commit kernel leaves the header in ring[slot])
             HIPC(hipEventRecord(c->ring_ev[slot], c->stream));
             ++issued;
         }
