@@ -94,16 +94,24 @@ int pwr_dims(pwr_ctx *ctx, int *rows, int *width);
 /* MMA_Auslesen (PW:1556-1598) into memory: rows*width characters, row-major, no newlines. */
 int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
 
-/* Knobs and counters (ours). keys: "window" (max rows filled speculatively per batch, 1..128),
- * "profile" (1 = time every fill launch with HIP events), "fill" (DP fill kernel: 4 = k_fill_v3, the default: one
- * work-group per pipeline wave; 3 = k_fill_v2: one work-group per DP, the independent cross-check and fallback, see
- * DESIGN.md 3.2), "waves" (waves per DP of the wave-pipeline fills: 9 (default), 8, 5, 4, 3, or 17 with k_fill_v3 only;
- * bandwidths above 1000 always use 9), "ptrace" (1 = speculative-parallel traceback k_trace_par, the default; 0 = one
- * wave per job), "slack" (spare column capacity kept when the device arrays are (re)allocated), "spec_len" (percent a
- * speculative row may be longer than the first row of its batch, default 6; results do not depend on it), "seg_rows" / "seg_max" /
- * "warm_pct" (k_fill_v3 fills a DP as up to seg_max segments of about seg_rows rows side by side, each warmed up while the band
- * moves by warm_pct percent of the bandwidth, and checks every one; seg_rows 0 = in one piece; results do not depend on them).
- * "fill", "waves", "slack" and the three "seg" options must be set before the first call that touches the device. */
+/* Knobs and counters (ours).  Results never depend on any of them.  keys:
+ *   "window"    rows gathered / filled per batch, the first certain to commit, the others speculative (1..128, default 3)
+ *   "profile"   1 = time every fill launch with HIP events (pwr_stats.fill_ms)
+ *   "fill"      DP fill kernel: 4 = k_fill_v3 (default: one work-group per pipeline wave, the DP in segments side by side);
+ *               3 = k_fill_v2 (one work-group per DP, in one piece: the independent cross-check and the stand-in after a stall)
+ *   "waves"     waves per DP segment of the wave-pipeline fills: 5 (default, 4 columns per lane), 9, 8, 4, 3, or 17 with
+ *               k_fill_v3 only; bandwidths above 1000 always use 9
+ *   "onewg"     1 = the waves of a k_fill_v3 segment form ONE work-group and hand over through LDS (default 0: measured slower)
+ *   "seg_rows", "seg_max", "warm_pct"
+ *               k_fill_v3 fills a DP as up to seg_max (<= 64, default 64) segments of about seg_rows (default 160) rows side
+ *               by side, each warmed up while the band moves by warm_pct (default 180) percent of the bandwidth, and CHECKS
+ *               every segment's start; a row whose check fails is repeated with twice the warm-up, then in
+ *               one piece (pwr_stats.seg_fails).  seg_rows 0 = always in one piece
+ *   "ptrace"    traceback kernel: 2 = k_trace_blk (default: one wave per 64 rows, no hand-over chain), 1 = k_trace_par (64 chunks
+ *               handing over top-down), 0 = k_trace_wp (one wave per job)
+ *   "slack"     spare column capacity kept when the device arrays are (re)allocated
+ *   "spec_len"  percent a speculative row may be longer than the first row of its batch (default 6)
+ * "fill", "waves", "slack" and the "seg" options must be set before the first call that touches the device. */
 int pwr_set_option(pwr_ctx *ctx, const char *key, long value);
 int pwr_get_option(pwr_ctx *ctx, const char *key, long *value);
 int pwr_get_stats(pwr_ctx *ctx, pwr_stats *out);

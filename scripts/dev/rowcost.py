@@ -1,28 +1,27 @@
-"""dev (GPU box): ns per DP row of single realignments (window 1) on a workload, product library.  usage: rowcost.py [workload] [n]"""
+"""dev (GPU box): what a DP row costs -- single realignments (window 1) of a workload, product library.
+Per realignment: the fill launch's duration (k_fill_v3 + k_seg_check, HIP events) over the row's length = the EFFECTIVE
+time per DP row of the chain (the segments of a fill run side by side), in ns and cycles; with seg_rows=0 the same in one
+piece = what a DP row costs the wave pipeline itself.   usage: rowcost.py [workload] [n] [key=value ...]"""
 import os, sys
 sys.path.insert(0, ".")
 from repeatresolver_amd import datagen as dg
 from repeatresolver_amd.realigner import PWReAligner
-wl = sys.argv[1] if len(sys.argv) > 1 else "tree_default"
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+args = [a for a in sys.argv[1:] if "=" not in a]
+opts = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}
+wl = args[0] if args else "tree_default"
+n = int(args[1]) if len(args) > 1 else 24
 rows = [bytes(r) for r in dg.make_msa(wl)]
-print(wl, len(rows), "rows x", len(rows[0]))
-for win in (1, 8):
-    g = PWReAligner(rows, bandwidth=1000, window=win, profile=True)
+print(wl, len(rows), "rows x", len(rows[0]), opts)
+for label, o in (("segments (default)", {}), ("one piece (seg_rows=0)", {"seg_rows": 0})):
+    g = PWReAligner(rows, bandwidth=1000, window=1, profile=True, **{**opts, **o})
     g.trim_ends(); g.total_score()
-    if win == 1:
-        tot_us = tot_L = 0
-        for k in range(n):
-            g.realign_row(k)
-            mhz, us = g.debug_fill_clock()
-            L = g.debug_last_job()["L"]
-            tot_us += us; tot_L += L
-            if k < 8:
-                print(f"  row {k}: L={L} fill {us:.0f} us = {1e3*us/max(L,1):.1f} ns/DP row = {mhz*us/max(L,1):.0f} cycles/row at {mhz:.0f} MHz")
-        print(f"window 1: {1e3*tot_us/tot_L:.1f} ns per DP row over {n} rows")
-    else:
-        g.realign_rows(0, 400)
-        st = g.stats()
-        import numpy as np
-        print(f"window {win}: 400 rows, {st['fill_launches']} launches, avg {st['fill_ms']/st['fill_launches_timed']:.3f} ms; committed {st['rows_committed']} recomputed {st['rows_recomputed']}")
+    g.realign_row(0); g.reset_stats()
+    tot_L = 0
+    for k in range(1, n + 1):
+        g.realign_row(k)
+        tot_L += g.debug_last_job()["L"]
+    st = g.stats()
+    ns = 1e6 * st["fill_ms"] / tot_L
+    print(f"{label}: {n} realignments, {tot_L} DP rows, fill {st['fill_ms']:.2f} ms in {st['fill_launches_timed']} launches = {ns:.1f} ns per DP row "
+          f"= {ns * 2.4:.0f} cycles at 2.4 GHz; segments per fill {st['segs'] / max(1, st['seg_jobs']):.1f}, check failures {st['seg_fails']}")
     g.close()
