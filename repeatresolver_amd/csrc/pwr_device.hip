@@ -2066,7 +2066,7 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
     const int job = blockIdx.x, lane = threadIdx.x;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail) return;
+    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -2233,7 +2233,7 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
     const unsigned ttag = jb.trace_tag;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail) return;
+    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -2488,7 +2488,7 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
     const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail) return;
+    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
     const int nch = (L + 63) >> 6;
     // the top chunks first: they are the ones everybody else waits for
     const int c = nch - 1 - UNI((int)blockIdx.y * TB_W + (tid >> 6));
