@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--spec-len", type=int, default=None, help="percent a speculative row may be longer than its batch's first row")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="any other knob of pwr_set_option (include/pwr.h), e.g. seg_rows=512")
+    ap.add_argument("--time-every", type=int, default=8, help="HIP events around every n-th fill launch (an event record costs ~6 us of stream time; 1 = every launch)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--deadline-s", type=float, default=500.0,
                     help="N = 1: once the process has run this long, the line is printed for the steps finished so far (no further step is started)")
@@ -174,7 +175,7 @@ def main():
     ctxs = []
     score0 = 0
     for _, urows in units:
-        g = PWReAligner(urows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=True, fill=args.fill, waves=args.waves,
+        g = PWReAligner(urows, bandwidth=args.bandwidth, device=dev, window=args.window, profile=args.time_every, fill=args.fill, waves=args.waves,
                         **{kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.opt})
         if args.spec_len is not None:
             g.set_option("spec_len", args.spec_len)
@@ -293,7 +294,8 @@ def main():
                          "cells_reference": st["cells_reference"], "cells_computed": st["cells_computed"],
                          "note": "achieved = DP cells computed by the fill kernel (the warm-up rows of its segments and speculative fills that were "
                                  "thrown away included: config.useful_frac of them are cells the reference fills) x 4 B / sum of HIP-event durations of "
-                                 "its launches (with its segment check) on the context's stream (rank 0's contexts); frac_useful_cells counts only the reference's cells"},
+                                 "its launches (with its segment check) on the context's stream (rank 0's contexts) -- every launches/launches_timed-th launch is bracketed, "
+                                 "an event record costs ~6 us of stream time; frac_useful_cells counts only the reference's cells"},
         }
         if per_rank is not None:
             out["per_rank"] = per_rank

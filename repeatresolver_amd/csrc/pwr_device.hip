@@ -61,7 +61,8 @@ struct Hdr {                       // lives in device memory, one per context
     unsigned long long ahead;      // bit b: row next_row + b was committed ahead of an earlier, stale row it commutes with (its band
                                    // interval is disjoint from that row's), so the batches to come leave it out
     int noseg_row;                 // this row's segmented fill failed its check (-1: none) ...
-    int noseg_level, pad2;         // ... once: its next fill warms up twice as long; twice: it runs in one piece
+    int noseg_level;               // ... once: its next fill warms up twice as long; twice: it runs in one piece
+    unsigned seq;                  // host copy only: which batch this copy of the header belongs to (written last)
     int need64;                    // > 0: a job needed the 64-bit fill lately; the host launches k_fill64 with the batches while this counts down
     unsigned long long dbg[32];    // phase timers of commit and trace (10 ns ticks), only written by builds with -DPWR_DIAG
 };
@@ -3140,7 +3141,20 @@ __device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsig
 // always invalidated while the MSA is still moving, so speculate just past the running mean of rows committed per batch --
 // and never let a speculative row make the batch longer than its first row, the only one that is certain to commit (a fill
 // takes time proportional to the row's length).
-__global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs jb, int njobs, const int *rowids, Hdr *host_copy)
+// The header as it stands after a batch goes to pinned host memory straight from the commit kernel: every word but the
+// sequence number, a system-scope fence, then the number -- the host polls that word, no copy command and no event record
+// (6 us each on the stream) behind every batch.
+__device__ __forceinline__ void publish_header(const Hdr *h, Hdr *host_copy, unsigned seq)
+{
+    if (!host_copy) return;
+    constexpr int NWORDS = (int)(sizeof(Hdr) / 4), SEQW = (int)(offsetof(Hdr, seq) / 4);
+    if ((int)threadIdx.x < NWORDS && (int)threadIdx.x != SEQW) reinterpret_cast<volatile int *>(host_copy)[threadIdx.x] = reinterpret_cast<const int *>(h)[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { *reinterpret_cast<volatile unsigned *>(&host_copy->seq) = seq; __threadfence_system(); }
+}
+
+__global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs jb, int njobs, const int *rowids, Hdr *host_copy, unsigned host_seq)
 {
     __shared__ unsigned sh[COMMIT_NT / 64];
     __shared__ int s_i[12];
@@ -3152,8 +3166,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
     if (threadIdx.x == 0) { h->ncommitted = 0; h->stop = 0; }
     __syncthreads();
     if (h->status != 0 || h->need_grow) {
-        // (the host looks at its copy of the header after every batch: pinned host memory, written from here)
-        if (host_copy && threadIdx.x < sizeof(Hdr) / 4) reinterpret_cast<volatile int *>(host_copy)[threadIdx.x] = reinterpret_cast<const int *>(h)[threadIdx.x];
+        publish_header(h, host_copy, host_seq);
         return;
     }
     // Jobs in row order.  A stale job (its inputs were changed by a commit since the gather) is left for the next batch --
@@ -3259,10 +3272,9 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
         h->dbg[10] += __builtin_amdgcn_s_memrealtime() - ph_chain0; h->dbg[11] += 1;
 #endif
     }
-    // the header as it stands after this batch, for the host (pinned memory: no copy command behind every batch)
     __threadfence();
     __syncthreads();
-    if (host_copy && threadIdx.x < sizeof(Hdr) / 4) reinterpret_cast<volatile int *>(host_copy)[threadIdx.x] = reinterpret_cast<const int *>(h)[threadIdx.x];
+    publish_header(h, host_copy, host_seq);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3358,6 +3370,7 @@ struct pwr_ctx {
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int spec_len = 6;                     // percent a speculative row may be longer than the first row of its batch (option "spec_len")
     int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP; cross-check and fallback)
+    unsigned host_seq = 0;                // sequence number of the header copies the commit kernels leave in pinned memory
     int seen_fallback = 0, seen_need64 = 0;   // Hdr::fallback / need64 as the host last saw them: the batches it enqueues bring k_fill_v2 / k_fill64 along
     unsigned trace_epoch = 0;             // k_trace_par launch counter (22 bits)
     unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
@@ -3372,7 +3385,6 @@ struct pwr_ctx {
     size_t ev_used = 0;
     void *h_hdr = nullptr;                // pinned staging buffer for the device header
     void *h_ring = nullptr;               // pinned copies of the header, one per batch in flight
-    hipEvent_t ring_ev[8] = {};
     // all device allocations, for cleanup
     std::vector<void *> allocs;
 };
@@ -3443,7 +3455,6 @@ static void free_device(pwr_ctx *c)
     if (c->h_hdr) { (void)hipHostFree(c->h_hdr); c->h_hdr = nullptr; }
     if (c->h_ring) {
         (void)hipHostFree(c->h_ring); c->h_ring = nullptr;
-        for (auto &e : c->ring_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     }
     c->on_device = false;
 }
@@ -3762,7 +3773,9 @@ static int grow_state(pwr_ctx *c, long long growth)
 static int launch_fill(pwr_ctx *c, int njobs)
 {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    const bool timed = c->profile && c->ev_used < (size_t)(1 << 16);      // beyond that the launches are sampled no further
+    // (an event record costs about 6 us on the stream, two of them 3 % of a batch: with "profile" 1 every launch is timed,
+    // with "profile" n > 1 every n-th; pwr_stats.fill_launches_timed says how many the sum covers)
+    const bool timed = c->profile && (c->stats.fill_launches % (unsigned)c->profile) == 0 && c->ev_used < (size_t)(1 << 16);
     if (timed) {
         if (c->ev_used == c->ev_pool.size()) {
             hipEvent_t a, b;
@@ -3874,7 +3887,7 @@ static int check_status(pwr_ctx *c)
 // One speculative batch, enqueued without waiting: the rows rowids[next_row ...] (Hdr, at most `window` of them) are
 // gathered from the committed state, filled and traced side by side, then committed in row order by one work-group that stops
 // at the first row whose inputs an earlier commit of this batch has changed, moves next_row on and sizes the next batch.
-static int enqueue_batch(pwr_ctx *c, Hdr *host_copy)
+static int enqueue_batch(pwr_ctx *c, Hdr *host_copy, unsigned host_seq)
 {
     const int n = c->window;
     int rc;
@@ -3891,7 +3904,7 @@ static int enqueue_batch(pwr_ctx *c, Hdr *host_copy)
         else hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
     }
     else hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
-    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n, c->d_rowids, host_copy);
+    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n, c->d_rowids, host_copy, host_seq);
     HIPC(hipGetLastError());
     return PWR_OK;
 }
@@ -3908,9 +3921,10 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
         void *p = nullptr;
         if (hipHostMalloc(&p, sizeof(Hdr) * PWR_INFLIGHT, hipHostMallocDefault) != hipSuccess) return PWR_ERR_NOMEM;
         c->h_ring = p;
-        for (int i = 0; i < PWR_INFLIGHT; ++i) HIPC(hipEventCreateWithFlags(&c->ring_ev[i], hipEventDisableTiming));
+        memset(p, 0, sizeof(Hdr) * PWR_INFLIGHT);                              // (sequence numbers start at 1)
     }
     Hdr *ring = static_cast<Hdr *>(c->h_ring);
+    unsigned seqs[PWR_INFLIGHT] = {};
     const int kend = k0 + n;
     if (!resume) {
         // start the slab: rows [k0, kend), first batch sized like the host did before (the running mean carries over).
@@ -3935,13 +3949,29 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
     while (true) {
         while (issued < most && issued - looked < PWR_INFLIGHT) {
             const int slot = (int)(issued % PWR_INFLIGHT);
-            if ((rc = enqueue_batch(c, &ring[slot]))) return rc;               // (its commit kernel leaves the header in ring[slot])
-            HIPC(hipEventRecord(c->ring_ev[slot], c->stream));
+            if ((rc = enqueue_batch(c, &ring[slot], ++c->host_seq))) return rc;   // (its commit kernel leaves the header in ring[slot], this number last)
+            seqs[slot] = c->host_seq;
             ++issued;
         }
         if (looked == issued) { (void)hipStreamSynchronize(c->stream); return PWR_ERR_INTERNAL; }   // rows left although every batch commits one: cannot happen
         const int slot = (int)(looked % PWR_INFLIGHT);
-        HIPC(hipEventSynchronize(c->ring_ev[slot]));
+        {
+            // wait for that batch's header: poll the sequence number (pinned memory), look at the stream now and then in case
+            // it has died
+            volatile unsigned *sq = &ring[slot].seq;
+            for (unsigned long long spin = 1; *sq != seqs[slot]; ++spin) {
+                if ((spin & 0xfffffull) == 0 && hipStreamQuery(c->stream) == hipSuccess && *sq != seqs[slot]) {
+                    // the stream is idle and the header never came: a launch failed
+                    hipError_t e = hipGetLastError();
+                    fprintf(stderr, "pwr: a batch ended without its header (%s)\n", hipGetErrorString(e));
+                    return PWR_ERR_DEVICE;
+                }
+#if !defined(__HIP_DEVICE_COMPILE__)
+                __builtin_ia32_pause();
+#endif
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
         const Hdr h = ring[slot];
         ++looked;
         c->seen_fallback = h.fallback; c->seen_need64 = h.need64;
@@ -4082,7 +4112,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     // (capped: every work-group of a k_fill_v3 launch must be resident at once -- 9 of 128 threads per job -- and a
     // window beyond what one CU-full of jobs survives is of no use anyway)
     if (!strcmp(key, "window")) { if (value < 1 || value > 128 || c->on_device) return PWR_ERR_ARG; c->window = (int)value; return PWR_OK; }
-    if (!strcmp(key, "profile")) { c->profile = value ? 1 : 0; return PWR_OK; }
+    if (!strcmp(key, "profile")) { if (value < 0 || value > 1000000) return PWR_ERR_ARG; c->profile = (int)value; return PWR_OK; }
     if (!strcmp(key, "spec_len")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->spec_len = (int)value; return PWR_OK; }
     if (!strcmp(key, "fill")) { if (c->on_device || (value != 3 && value != 4)) return PWR_ERR_ARG; c->fill_mode = (int)value; return PWR_OK; }
     if (!strcmp(key, "stall_test")) { if (value < 0 || value > 1000000) return PWR_ERR_ARG; c->stall_test = (int)value; return PWR_OK; }
