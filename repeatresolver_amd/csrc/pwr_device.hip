@@ -494,9 +494,20 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_c(DState st, JobBufs jb)
             }
         }
     };
-    // pass 1: this share's sum of S(.,4)
+    // pass 1: this share's sum of S(.,4).  The tallies it reads (two dependent loads per column) are kept in registers for
+    // pass 2, for the first GC_K columns of every thread -- all of them unless the interval is longer than 49 000 columns
+    constexpr int GC_K = 6;
+    uint32_t cw[GC_K][6];
     unsigned mysum = 0;
-    for (int i = i0 + tid; i < i1; i += GATHER_NT) { uint32_t w[6]; tally_of(lo + i, w, nullptr); mysum += w[4]; }
+    unsigned long long ucost = 0;                                                    // cost of the row where it stands now: an upper bound of the optimum
+#pragma unroll
+    for (int it = 0; it < GC_K; ++it) {
+        const int i = i0 + tid + it * GATHER_NT;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) cw[it][b] = 0;
+        if (i < i1) { tally_of(lo + i, cw[it], &ucost); mysum += cw[it][4]; }
+    }
+    for (int i = i0 + tid + GC_K * GATHER_NT; i < i1; i += GATHER_NT) { uint32_t w[6]; tally_of(lo + i, w, nullptr); mysum += w[4]; }
     for (int o = 32; o > 0; o >>= 1) mysum += __shfl_xor(mysum, o);
     if ((tid & 63) == 0) sh[tid >> 6] = mysum;
     __syncthreads();
@@ -518,15 +529,22 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_c(DState st, JobBufs jb)
     __syncthreads();
     // pass 2: the records
     unsigned carry = s_carry, maxS = 0;
-    unsigned long long ucost = 0;                                                    // cost of the row where it stands now: an upper bound of the optimum
     if (tid == 0) s_cov[0] = s_covl;
     __syncthreads();
-    for (int base = i0; base < i1; base += GATHER_NT) {
+    int it2 = 0;
+    for (int base = i0; base < i1; base += GATHER_NT, ++it2) {
         const int i = base + tid;
         const bool valid = i < i1;
         const int y = lo + i;
         uint32_t w[6] = {0, 0, 0, 0, 0, 0};
-        if (valid) tally_of(y, w, &ucost);
+        if (it2 < GC_K) {
+#pragma unroll
+            for (int k = 0; k < GC_K; ++k)
+                if (it2 == k) {
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) w[b] = cw[k][b];
+                }
+        } else if (valid) tally_of(y, w, &ucost);
         unsigned tot;
         const unsigned gin = block_incl_add<GATHER_NT>(w[4], sh, tot);               // barriers inside
         s_cov[tid + 1] = w[5];
