@@ -41,8 +41,8 @@ class PWReAligner:
             _check(self._lib.pwr_set_option(self._h, b"waves", int(waves)), "set waves")
         if fill is not None:
             _check(self._lib.pwr_set_option(self._h, b"fill", int(fill)), "set fill")
-        if profile:
-            _check(self._lib.pwr_set_option(self._h, b"profile", 1), "set profile")
+        if profile:                                  # True / 1: HIP events around every fill launch; n > 1: around every n-th
+            _check(self._lib.pwr_set_option(self._h, b"profile", int(profile)), "set profile")
         for key, value in options.items():           # any other knob of pwr_set_option (include/pwr.h), e.g. seg_rows
             _check(self._lib.pwr_set_option(self._h, key.encode(), int(value)), "set " + key)
 
