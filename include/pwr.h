@@ -102,11 +102,12 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
  *   "waves"     waves per DP segment of the wave-pipeline fills: 5 (default, 4 columns per lane), 9, 8, 4, 3, or 17 with
  *               k_fill_v3 only; bandwidths above 1000 always use 9
  *   "onewg"     1 = the waves of a k_fill_v3 segment form ONE work-group and hand over through LDS (default 0: measured slower)
- *   "seg_rows", "seg_max", "warm_pct"
+ *   "seg_rows", "seg_max", "warm_pct", "seg_align"
  *               k_fill_v3 fills a DP as up to seg_max (<= 64, default 64) segments of about seg_rows (default 160) rows side
  *               by side, each warmed up while the band moves by warm_pct (default 180) percent of the bandwidth, and CHECKS
  *               every segment's start; a row whose check fails is repeated with twice the warm-up, then in
- *               one piece (pwr_stats.seg_fails).  seg_rows 0 = always in one piece
+ *               one piece (pwr_stats.seg_fails).  seg_rows 0 = always in one piece; seg_align (16, 32, 64): the segments' first rows are
+ *               multiples of it
  *   "ptrace"    traceback kernel: 2 = k_trace_blk (default: one wave per 64 rows, no hand-over chain), 1 = k_trace_par (64 chunks
  *               handing over top-down), 0 = k_trace_wp (one wave per job)
  *   "slack"     spare column capacity kept when the device arrays are (re)allocated

@@ -151,6 +151,7 @@ struct JobBufs {
     unsigned long long *gmb;       // [njobs][NW][gstride][2] k_fill_v3: {P_end, tag}, {M_last, tag} per wave and DP row (segments side by side)
     SegDesc *seg;                  // [njobs][SEG_MAX] plan of the fill (plan_segments, with k_gather_c)
     unsigned *chk;                 // [njobs][SEG_MAX + 1][2][NC] scores of the row before segment s: [0] as s has them after its warm-up, [1] as s - 1 ends
+    int seg_align;                 // own parts start at multiples of this (16, 32 or 64)
     int smax, seg_rows, warm_cols; // at most smax segments per job, of about seg_rows own rows, warmed up over warm_cols columns of band movement
     int gstride;                   // rows per wave of a job's mailbox area
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, c
 }
 
 // The plan of a job's fill (one work-group): how many segments, where each starts to warm up, the cells it computes.
-// Own parts start at multiples of 64 rows; a warm-up starts at the last multiple of 16 (the fill stores its record per 16 rows)
+// Own parts and warm-ups start at multiples of 16 rows (the fill stores its record per 16 rows): a warm-up at the last one
 // whose band lies at least warm_cols columns left of the own part's first band.  A row whose check failed is planned again
 // with twice the warm-up, and in one piece if that fails too (Hdr::noseg_row / noseg_level).
 __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
@@ -410,7 +411,7 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
     if (tid < SEG_MAX) s_cells[tid] = 0;
     __syncthreads();
     const int S = s_S, warm = s_warm;
-    if (tid <= S) s_x[tid] = tid == S ? L : (int)(((long long)L * tid / S) & ~63ll);
+    if (tid <= S) s_x[tid] = tid == S ? L : (int)(((long long)L * tid / S) & ~(long long)(jb.seg_align - 1));   // (a multiple of 16: the record is stored per 16 rows)
     __syncthreads();
     if (tid < S) {
         int xb = 0;
@@ -3395,6 +3396,7 @@ struct pwr_ctx {
     int wp_waves = 5;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane (5: measured best with segments side by side)
     int one_wg = 0;                       // k_fill_v3: the waves of a segment as one work-group (hand-over through LDS); 0: one work-group per wave
     int seg_rows = 160;                   // k_fill_v3: a DP is filled in segments of about this many rows, side by side (0: in one piece)
+    int seg_align = 16;                   // ... whose own parts start at multiples of this many rows (16 / 32 / 64)
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
     int warm_pct = 180;                   // ... each warmed up while the band moves by this many percent of the bandwidth
     // stats
@@ -3568,6 +3570,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     jb.wpMS = 64 * wpC;
     if ((rc = dmalloc(c, &jb.lastM, (size_t)njobs * jb.NC))) return rc;
     jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
+    jb.seg_align = c->seg_align;
     jb.seg_rows = c->fill_mode == 4 ? c->seg_rows : 0;
     jb.warm_cols = (int)std::min<long long>((long long)c->B * c->warm_pct / 100 + 2, 1 << 20);
     jb.gstride = jb.Lmax + jb.smax * (2 * jb.warm_cols + 64);          // (a row whose check failed warms up twice as long)
@@ -4143,6 +4146,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "trace_epoch")) { if (value < 0 || value >= (1 << 14)) return PWR_ERR_ARG; c->trace_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "onewg")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->one_wg = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_rows")) { if (c->on_device || value < 0 || value > 1000000) return PWR_ERR_ARG; c->seg_rows = (int)value; return PWR_OK; }
+    if (!strcmp(key, "seg_align")) { if (c->on_device || (value != 16 && value != 32 && value != 64)) return PWR_ERR_ARG; c->seg_align = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_pct")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->warm_pct = (int)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9 && value != 17)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }

@@ -54,7 +54,7 @@ def test_failed_segment_check_repeats_the_row_in_one_piece(oracle):
 
 def test_cells_computed_count_the_warm_up_rows(oracle):
     """pwr_stats.cells_computed (the numerator of bench.py's roofline figure) against the plan restated here: segment s of
-    a row owns the rows [x_s, x_{s+1}), x_s = floor(L s / S) rounded down to 64, and warms up from the last multiple of 16
+    a row owns the rows [x_s, x_{s+1}), x_s = floor(L s / S) rounded down to 16, and warms up from the last multiple of 16
     whose base lies at least warm_cols columns left of base x_s; every row of it costs min(B, W - anf) cells."""
     from repeatresolver_amd.realigner import PWReAligner
     rows = split_rows(golden_input("toy_b_b1000"))
@@ -76,7 +76,7 @@ def test_cells_computed_count_the_warm_up_rows(oracle):
         way = np.ctypeslib.as_array(lib.pwo_dbg_way(h), (L,)).astype(np.int64)
         cells = np.minimum(bw, W - np.maximum(0, way - H))
         S = max(1, min((L + sr // 2) // sr, smax, L // 128))
-        xs = [(L * s // S) & ~63 for s in range(S)] + [L]
+        xs = [(L * s // S) & ~15 for s in range(S)] + [L]
         for s in range(S):
             xb = 0
             if s > 0:
