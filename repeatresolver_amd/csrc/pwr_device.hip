@@ -80,7 +80,7 @@ struct Tally {                     // 32 B per column slot
     uint32_t pad;
 };
 
-struct JobMeta {                   // 88 B
+struct JobMeta {                   // 96 B
     int k, L, lo, hi, W, entry, ok, nnew;
     unsigned maxS;
     int ver;                       // hdr->version when the job's inputs were gathered
@@ -92,6 +92,7 @@ struct JobMeta {                   // 88 B
     int active;                    // 0: the job slot is unused in this batch (everything else is left from the last use)
     int wide;                      // 1: the scores may not fit 32 bits: k_fill64 fills this job, the wave pipeline skips it
     int off, pad;                  // the job's row is rowids[next_row + off]
+    int changed, pad3;             // 0: the traceback left every base where it was (k_trace_blk): the commit has nothing to do
     int nseg, segfail;             // segments the fill was cut into (k_fill_v3); 1: a segment's warm-up had not converged, the job is repeated in one piece
 };
 
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, c
         jb.gpart[(size_t)job * GATHER_G + g].cells = cs;
         if (g == 0) {
             m->k = k; m->L = L; m->lo = lo; m->hi = hi; m->W = W; m->entry = -1; m->nnew = 0; m->abort = 0; m->active = 1; m->off = boff;
-            m->ver = hd->version; m->slot_lo = order[lo]; m->slot_hi = order[hi]; m->ok = 1;
+            m->ver = hd->version; m->slot_lo = order[lo]; m->slot_hi = order[hi]; m->ok = 1; m->changed = 0;
         }
     }
 }
@@ -2223,6 +2224,7 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
     if (!err && blk * 64 + lane < L) newcol[blk * 64 + lane] = ncreg;
     if (lane == 0) {
         m->nnew = nnew;
+        m->changed = 1;                                       // (not worked out here: the commit takes the long way)
         if (err) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
     }
 }
@@ -2477,6 +2479,7 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
         for (int c = 1; c < nch; ++c)                       // all chunks above are final (hand-over order) and posted
             tot += (int)((__hip_atomic_load(&hand[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 24) & 0xffffull);
         m->nnew = tot;
+        m->changed = 1;                                     // (not worked out here: the commit takes the long way)
     }
 }
 
@@ -2758,6 +2761,8 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
         if (!err) { TB_POST(2, arr) }
     }
     if (x_lo + lane < L) { newcol[x_lo + lane] = ncreg; yin[x_lo + lane] = yireg; }
+    // did any base of the chunk move (or open a column)?  If none of the row's does, its commit has nothing to do.
+    if (__ballot(x_lo + lane < L && ncreg != (wcur << 1)) != 0ull && lane == 0) __hip_atomic_store(&m->changed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (top || err) {
         if (lane == 0)
             __hip_atomic_store(&hand[c], TB_WORD(ttag, err ? 3 : 2, cnt, 0, (unsigned)(yexit + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2833,6 +2838,14 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     const int nfree = h->nfree, nslots = h->nslots;
     const int take = min(nnew, nfree);
     const unsigned newver = (unsigned)h->version + 1u;
+    if (!m->changed && st.nbrk[k] == 0) {
+        // The traceback put every base back where it was and opened no column (k_trace_blk): no tally, no slot, no ordinal
+        // changes -- most rows of the later rounds.  (A row read with blank runs between its bases is joined by its first
+        // commit even then: it takes the long way.)
+        if (tid == 0) h->cells_reference += m->cells;
+        __syncthreads();
+        return;
+    }
     PH_T0()
     if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[3] = 0; s_i[4] = 0x7fffffff; s_i[5] = 0; s_i[8] = 0; }   // [8] changed columns, [0] freed slots, [1] some column lost its last base, [3] any change, [4] first ordinal that changes, [5] structural events
     {
