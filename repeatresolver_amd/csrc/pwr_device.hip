@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -3422,6 +3423,25 @@ struct pwr_ctx {
     std::vector<void *> allocs;
 };
 
+// The host's passes over the text (1.8 GB at benchmark scale: parse, EntAlGapper, the first tallies) are row-parallel:
+// f(r0, r1, t) for contiguous shares of the rows on up to 16 threads.
+template <class F>
+static void par_rows(int T, F f)
+{
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    nt = (unsigned)std::max(1, std::min<int>((int)nt, T / 64));
+    if (nt <= 1) { f(0, T, 0); return; }
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([=]() { f((int)((long long)T * t / nt), (int)((long long)T * (t + 1) / nt), (int)t); });
+    for (auto &x : th) x.join();
+}
+static unsigned par_threads(int T)
+{
+    unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    return (unsigned)std::max(1, std::min<int>((int)nt, T / 64));
+}
+
 static int code_of_char(unsigned char c)
 {
     switch (c) {   // PW:165-222
@@ -3468,11 +3488,15 @@ extern "C" int pwr_create(pwr_ctx **out, int rows, int width, const unsigned cha
     c->T = rows; c->B = bandwidth; c->H = bandwidth / 2; c->device = device;   // PW:1625-1626
     c->W_host = width;
     try { c->text.resize((size_t)rows * width); } catch (...) { delete c; return PWR_ERR_NOMEM; }
-    for (size_t i = 0; i < (size_t)rows * width; ++i) {
-        const int s = code_of_char(text[i]);
-        if (s < 0) { delete c; return PWR_ERR_INPUT; }
-        c->text[i] = (unsigned char)s;
-    }
+    std::vector<int> bad(par_threads(rows), 0);
+    par_rows(rows, [&](int r0, int r1, int t) {
+        for (size_t i = (size_t)r0 * width; i < (size_t)r1 * width; ++i) {
+            const int s = code_of_char(text[i]);
+            if (s < 0) { bad[t] = 1; return; }
+            c->text[i] = (unsigned char)s;
+        }
+    });
+    for (int b : bad) if (b) { delete c; return PWR_ERR_INPUT; }
     *out = c;
     return PWR_OK;
 }
@@ -3523,32 +3547,42 @@ static void dfree(pwr_ctx *c, void *p)
 static void host_trim(pwr_ctx *c)
 {
     const int T = c->T, W = c->W_host;
-    std::vector<unsigned char> has(W, 0);
-    for (int r = 0; r < T; ++r) {
-        const unsigned char *row = &c->text[(size_t)r * W];
-        for (int i = 0; i < W; ++i) has[i] |= (row[i] < 4);
-    }
+    const unsigned nth = par_threads(T);
+    std::vector<std::vector<unsigned char>> hasp(nth, std::vector<unsigned char>(W, 0));
+    par_rows(T, [&](int r0, int r1, int t) {
+        unsigned char *has = hasp[t].data();
+        for (int r = r0; r < r1; ++r) {
+            const unsigned char *row = &c->text[(size_t)r * W];
+            for (int i = 0; i < W; ++i) has[i] |= (row[i] < 4);
+        }
+    });
     std::vector<int> keep;
     keep.reserve(W);
-    for (int i = 0; i < W; ++i) if (has[i]) keep.push_back(i);
+    for (int i = 0; i < W; ++i) {
+        unsigned char h = 0;
+        for (unsigned t = 0; t < nth; ++t) h |= hasp[t][i];
+        if (h) keep.push_back(i);
+    }
     const int n = (int)keep.size();
     std::vector<unsigned char> nt((size_t)T * n);
-    for (int r = 0; r < T; ++r) {
-        const unsigned char *row = &c->text[(size_t)r * W];
-        unsigned char *o = &nt[(size_t)r * n];
-        bool prev_blank = true;
-        for (int i = 0; i < n; ++i) {
-            unsigned char s = row[keep[i]];
-            if (s == 4 && prev_blank) s = 5;
-            prev_blank = (s == 5);
-            o[i] = s;
+    par_rows(T, [&](int r0, int r1, int) {
+        for (int r = r0; r < r1; ++r) {
+            const unsigned char *row = &c->text[(size_t)r * W];
+            unsigned char *o = &nt[(size_t)r * n];
+            bool prev_blank = true;
+            for (int i = 0; i < n; ++i) {
+                unsigned char s = row[keep[i]];
+                if (s == 4 && prev_blank) s = 5;
+                prev_blank = (s == 5);
+                o[i] = s;
+            }
+            bool next_blank = true;
+            for (int i = n - 1; i >= 0; --i) {
+                if (o[i] == 4 && next_blank) o[i] = 5;
+                next_blank = (o[i] == 5);
+            }
         }
-        bool next_blank = true;
-        for (int i = n - 1; i >= 0; --i) {
-            if (o[i] == 4 && next_blank) o[i] = 5;
-            next_blank = (o[i] == 5);
-        }
-    }
+    });
     c->text.swap(nt);
     c->W_host = n;
 }
@@ -3631,26 +3665,44 @@ static int upload(pwr_ctx *c)
     std::vector<uint32_t> w((size_t)W0 * 6, 0);
     std::vector<long long> rowoff(T + 1, 0);
     c->rowlen.assign(T, 0);
-    for (int r = 0; r < T; ++r) {
-        const unsigned char *row = &c->text[(size_t)r * W0];
-        int first = -1, last = -1, L = 0;
+    {
+        // (row-parallel: per-thread symbol counts per column -- 7 counters, "not b" tallies derived at the end)
+        const unsigned nth = par_threads(T);
+        std::vector<std::vector<uint32_t>> cnt(nth, std::vector<uint32_t>((size_t)W0 * 6, 0));   // counts of symbols 0..5 per column
+        std::vector<int> errs(nth, 0);
+        par_rows(T, [&](int r0, int r1, int t) {
+            uint32_t *ct = cnt[t].data();
+            for (int r = r0; r < r1; ++r) {
+                const unsigned char *row = &c->text[(size_t)r * W0];
+                int L = 0;
+                for (int i = 0; i < W0; ++i) {
+                    const int s = row[i];
+                    L += s < 4;
+                    ct[(size_t)i * 6 + s] += 1;
+                }
+                // every maximal run of non-blank cells must be a segment base..base (what EntAlGapper, PW:459-645, leaves behind)
+                for (int i = 0; i < W0; ++i) {
+                    if (row[i] == 5) continue;
+                    int j = i;
+                    while (j + 1 < W0 && row[j + 1] != 5) ++j;
+                    if (row[i] >= 4 || row[j] >= 4) { errs[t] = PWR_ERR_UNSUPPORTED; return; }
+                    i = j;
+                }
+                if (L > PWR_MAX_SEQ_LENGTH) { errs[t] = PWR_ERR_RANGE; return; }   // PW:675-680
+                c->rowlen[r] = L;
+            }
+        });
+        for (int e : errs) if (e == PWR_ERR_UNSUPPORTED) return e;
+        for (int e : errs) if (e) return e;
+        // w[b] = rows non-blank and != b (PW:165-222) = (non-blank rows) - (rows with symbol b)
         for (int i = 0; i < W0; ++i) {
-            const int s = row[i];
-            if (s < 4) { if (first < 0) first = i; last = i; ++L; }
-            if (s != 5) for (int b = 0; b < 6; ++b) if (b != s) w[(size_t)i * 6 + b] += 1;
+            uint32_t n[6] = {0, 0, 0, 0, 0, 0};
+            for (unsigned t = 0; t < nth; ++t) for (int b = 0; b < 6; ++b) n[b] += cnt[t][(size_t)i * 6 + b];
+            const uint32_t cov = n[0] + n[1] + n[2] + n[3] + n[4];
+            for (int b = 0; b < 5; ++b) w[(size_t)i * 6 + b] = cov - n[b];
+            w[(size_t)i * 6 + 5] = cov;
         }
-        // every maximal run of non-blank cells must be a segment base..base (what EntAlGapper, PW:459-645, leaves behind)
-        for (int i = 0; i < W0; ++i) {
-            if (row[i] == 5) continue;
-            int j = i;
-            while (j + 1 < W0 && row[j + 1] != 5) ++j;
-            if (row[i] >= 4 || row[j] >= 4) return PWR_ERR_UNSUPPORTED;
-            i = j;
-        }
-        (void)first; (void)last;
-        if (L > PWR_MAX_SEQ_LENGTH) return PWR_ERR_RANGE;                     // PW:675-680
-        c->rowlen[r] = L;
-        rowoff[r + 1] = rowoff[r] + L;
+        for (int r = 0; r < T; ++r) rowoff[r + 1] = rowoff[r] + c->rowlen[r];
     }
     c->sumL = rowoff[T];
     c->Lmax = 0;
@@ -3667,23 +3719,37 @@ static int upload(pwr_ctx *c)
     std::vector<int> pos(std::max<long long>(c->sumL, 1));
     std::vector<long long> brkoff(T + 1, 0);
     std::vector<int> brkx, nbrk(T, 0);
-    for (int r = 0; r < T; ++r) {
-        const unsigned char *row = &c->text[(size_t)r * W0];
-        long long o = rowoff[r];
-        int last = -1;
-        brkoff[r] = (long long)brkx.size();
-        for (int i = 0; i < W0; ++i) {
-            if (row[i] < 4) { seq[o] = row[i]; pos[o] = colidx[i]; last = colidx[i]; ++o; }
-            else if (row[i] == 5 && last >= 0 && i > 0 && row[i - 1] != 5) {
-                // a segment ends in the column before: an inner end if more bases follow (settled below)
-                brkx.push_back((int)(o - rowoff[r]) - 1);
+    {
+        // (row-parallel; the breaks and the segment ends a thread finds are merged in row order afterwards)
+        const unsigned nth = par_threads(T);
+        std::vector<std::vector<int>> tb(nth), tend(nth);       // per thread: break indices of its rows in order; columns that end a segment
+        par_rows(T, [&](int r0, int r1, int t) {
+            std::vector<int> &bx = tb[t], &en = tend[t];
+            for (int r = r0; r < r1; ++r) {
+                const unsigned char *row = &c->text[(size_t)r * W0];
+                long long o = rowoff[r];
+                int last = -1;
+                const size_t b0 = bx.size();
+                for (int i = 0; i < W0; ++i) {
+                    if (row[i] < 4) { seq[o] = row[i]; pos[o] = colidx[i]; last = colidx[i]; ++o; }
+                    else if (row[i] == 5 && last >= 0 && i > 0 && row[i - 1] != 5) {
+                        // a segment ends in the column before: an inner end if more bases follow (settled below)
+                        bx.push_back((int)(o - rowoff[r]) - 1);
+                    }
+                }
+                // the blank run after the row's LAST base is its margin, not a break
+                while (bx.size() > b0 && bx.back() == c->rowlen[r] - 1) bx.pop_back();
+                nbrk[r] = (int)(bx.size() - b0);
+                for (size_t q = b0; q < bx.size(); ++q) en.push_back(pos[rowoff[r] + bx[q]]);
+                if (last >= 0) en.push_back(last);
             }
+        });
+        for (unsigned t = 0; t < nth; ++t) {
+            brkx.insert(brkx.end(), tb[t].begin(), tb[t].end());
+            for (int col : tend[t]) tal[col].endcnt += 1;
         }
-        // the blank run after the row's LAST base is its margin, not a break
-        while ((long long)brkx.size() > brkoff[r] && brkx.back() == c->rowlen[r] - 1) brkx.pop_back();
-        nbrk[r] = (int)((long long)brkx.size() - brkoff[r]);
-        for (long long t = brkoff[r]; t < (long long)brkx.size(); ++t) tal[pos[rowoff[r] + brkx[t]]].endcnt += 1;
-        if (last >= 0) tal[last].endcnt += 1;
+        long long acc = 0;
+        for (int r = 0; r < T; ++r) { brkoff[r] = acc; acc += nbrk[r]; }
     }
     brkoff[T] = (long long)brkx.size();
     // capacities
@@ -4061,15 +4127,20 @@ extern "C" int pwr_total_score(pwr_ctx *c, uint64_t *total)
     if (!c->on_device) {
         // host state (before the first device call): literal PW:864-892 on the code matrix
         const int T = c->T, W = c->W_host;
-        std::vector<uint32_t> w((size_t)W * 6, 0);
-        for (int r = 0; r < T; ++r)
-            for (int i = 0; i < W; ++i) {
-                const int s = c->text[(size_t)r * W + i];
-                if (s != 5) for (int b = 0; b < 6; ++b) if (b != s) w[(size_t)i * 6 + b] += 1;
-            }
+        const unsigned nth = par_threads(T);
+        std::vector<std::vector<uint32_t>> cnt(nth, std::vector<uint32_t>((size_t)W * 6, 0));   // rows with symbol 0..5, per column
+        par_rows(T, [&](int r0, int r1, int t) {
+            uint32_t *ct = cnt[t].data();
+            for (int r = r0; r < r1; ++r)
+                for (int i = 0; i < W; ++i) ct[(size_t)i * 6 + c->text[(size_t)r * W + i]] += 1;
+        });
         uint64_t tot = 0;
-        for (int i = 0; i < W; ++i)
-            for (int b = 0; b < 5; ++b) tot += (uint64_t)(w[(size_t)i * 6 + 5] - w[(size_t)i * 6 + b]) * w[(size_t)i * 6 + b];
+        for (int i = 0; i < W; ++i) {
+            uint64_t n[5] = {0, 0, 0, 0, 0};
+            for (unsigned t = 0; t < nth; ++t) for (int b = 0; b < 5; ++b) n[b] += cnt[t][(size_t)i * 6 + b];
+            const uint64_t cov = n[0] + n[1] + n[2] + n[3] + n[4];
+            for (int b = 0; b < 5; ++b) tot += n[b] * (cov - n[b]);          // = (w[5] - w[b]) * w[b] with w[b] = cov - n[b]
+        }
         *total = tot;
         return PWR_OK;
     }

@@ -10,6 +10,7 @@ rows = [bytes(r) for r in dg.make_msa(wl)]
 g = PWReAligner(rows, bandwidth=1000)
 g.trim_ends()
 best = g.total_score()
+g.realign_rows(0, 0)                 # the MSA into HBM before the clock starts (the reference's clock starts after MMA_Einlesen too, PW:1679)
 print("rows", len(rows), "columns", len(rows[0]), "score", best, flush=True)
 t_all = time.time()
 out = []
