@@ -326,6 +326,55 @@ def test_sections_sharded_over_two_ranks_hip_worker(oracle):
         assert got[0][p] == exp, p
 
 
+def _nccl_single_rank_main(port, q):
+    """The RCCL code path itself (`nccl` backend, CUDA tensors in the all-gather), as far as one GPU allows: a process
+    group of ONE rank."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from conftest import golden_input, split_rows
+    from repeatresolver_amd.sharding import _allgather_bytes, realign_sections
+    from repeatresolver_amd.window import slice_sections
+    rows = split_rows(golden_input("toy_b_b1000"))
+    W = len(rows[0])
+    secs = slice_sections(rows, [0, W // 2, W])
+    out = realign_sections(secs, bandwidth=300, max_rounds=1)
+    blobs = _allgather_bytes(b"xGMI" * 1000, torch.device("cuda", 0))          # the collective with device tensors
+    q.put((out, blobs == [b"xGMI" * 1000], dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_path_runs_with_one_rank(oracle):
+    """No multi-GPU node is available to these tests, and RCCL refuses two ranks on one device; what CAN run is the `nccl`
+    branch of sharding.py under a one-rank RCCL process group: init, the all-gather of sizes and payloads on CUDA tensors,
+    barrier, teardown.  (The N > 1 behaviour is covered with gloo: two ranks, one GPU.)"""
+    import multiprocessing as mp
+    import socket
+    from conftest import golden_input, split_rows
+    from repeatresolver_amd.window import slice_sections
+    from test_window_sharding import _oracle_worker
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single_rank_main, args=(port, q))
+    p.start()
+    out, gathered, backend = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and backend == "nccl" and gathered
+    rows = split_rows(golden_input("toy_b_b1000"))
+    W = len(rows[0])
+    for sec, got in zip(slice_sections(rows, [0, W // 2, W]), out):
+        exp, _ = _oracle_worker(sec, 300, 0, 1)
+        assert got == exp
+
+
 def test_bench_two_ranks_rehearsal():
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), rehearsed on one GPU
     with gloo: ONE MSA cut into its Window.py sections, sections dealt to the ranks, strong scaling, per-rank times."""
