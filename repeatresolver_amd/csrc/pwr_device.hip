@@ -2855,14 +2855,10 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         for (int u = ((ny0 - lo) >> 3) + tid; u <= ((nyL - lo) >> 3); u += COMMIT_NT) m8[u] = 0ull;
     }
     __syncthreads();
-    for (int x = tid; x < L; x += COMMIT_NT) {
-        const int c = newcol[x];
-        if (!(c & 1)) mark2[(c >> 1) - lo] = (uint8_t)(st.seq[off + x] + 1);
-    }
-    __syncthreads();
     PH_ADD(h, 1)
-    // 1. new columns (PW:1245-1332) and the slot of every base.  The tallies of the neighbour column y
-    //    are read as the trace saw them: the row's old symbol taken out, the new one not yet put in.
+    // 1. new columns (PW:1245-1332), the slot of every base (into `pos` at once: nothing below reads this row's), and the
+    //    marks of the new placement.  The tallies of the neighbour column y are read as the trace saw them: the row's old
+    //    symbol taken out, the new one not yet put in.
     unsigned carry = 0;
     for (int base = 0; base < L; base += COMMIT_NT) {
         const int x = base + tid;
@@ -2896,8 +2892,11 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
                 atomicMin(&s_i[4], y);
                 { const int e = atomicAdd(&s_i[5], 1); if (e < EVCAP) { ev->key[e] = 2 * y + 1; ev->dl[e] = 1; } }   // a column opens after y
                 aux[x] = slot;
+                st.pos[off + x] = slot;
             } else {
                 aux[x] = sloty;
+                st.pos[off + x] = sloty;
+                mark2[y - lo] = (uint8_t)(st.seq[off + x] + 1);
             }
         }
     }
@@ -2950,8 +2949,6 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     }
     __syncthreads();
     PH_ADD(h, 3)
-    for (int x = tid; x < L; x += COMMIT_NT) st.pos[off + x] = aux[x];
-    __syncthreads();
     if (tid == 0) {
         const int oend = order[wayL], nend = aux[L - 1];
         if (oend != nend) { st.tally[oend].endcnt -= 1; st.tally[nend].endcnt += 1; }
