@@ -104,7 +104,7 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
  *   "onewg"     1 = the waves of a k_fill_v3 segment form ONE work-group and hand over through LDS (default 0: measured slower)
  *   "seg_rows", "seg_max", "warm_pct", "seg_align"
  *               k_fill_v3 fills a DP as up to seg_max (<= 64, default 64) segments of about seg_rows (default 160) rows side
- *               by side, each warmed up while the band moves by warm_pct (default 180) percent of the bandwidth, and CHECKS
+ *               by side, each warmed up while the band moves by warm_pct (default 190) percent of the bandwidth, and CHECKS
  *               every segment's start; a row whose check fails is repeated with twice the warm-up, then in
  *               one piece (pwr_stats.seg_fails).  seg_rows 0 = always in one piece; seg_align (16, 32, 64): the segments' first rows are
  *               multiples of it

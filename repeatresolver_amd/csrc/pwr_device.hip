@@ -3409,7 +3409,7 @@ struct pwr_ctx {
     int seg_rows = 160;                   // k_fill_v3: a DP is filled in segments of about this many rows, side by side (0: in one piece)
     int seg_align = 16;                   // ... whose own parts start at multiples of this many rows (16 / 32 / 64)
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
-    int warm_pct = 180;                   // ... each warmed up while the band moves by this many percent of the bandwidth
+    int warm_pct = 190;                   // ... each warmed up while the band moves by this many percent of the bandwidth
     // stats
     pwr_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
