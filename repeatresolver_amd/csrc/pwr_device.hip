@@ -415,30 +415,55 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
     const int S = s_S, warm = s_warm;
     if (tid <= S) s_x[tid] = tid == S ? L : (int)(((long long)L * tid / S) & ~(long long)(jb.seg_align - 1));   // (a multiple of 16: the record is stored per 16 rows)
     __syncthreads();
-    if (tid < S) {
-        int xb = 0;
-        if (tid > 0) {
-            // largest multiple of 16 below x_s whose row sits at least warm columns left of row x_s (Way[] is increasing)
-            const int xs = s_x[tid], lim = way[xs] - warm;
-            int a = 0, b = xs / 16 - 1;                       // candidates 16 * [0, b]
-            if (way[0] > lim) b = -1;
-            while (a < b) { const int mid = (a + b + 1) >> 1; if (way[16 * mid] <= lim) a = mid; else b = mid - 1; }
-            xb = b < 0 ? 0 : 16 * a;
+    {
+        // xb of segment s: the largest multiple of 16 below x_s whose row sits at least `warm` columns left of row x_s (Way[]
+        // is increasing).  Sixteen threads per segment, a 16-ary search: three dependent loads instead of twelve (this share
+        // would otherwise be the one its kernel waits for).
+        static_assert(SEG_MAX * 16 <= GATHER_NT, "sixteen threads per segment");
+        const int sgi = tid >> 4, li = tid & 15;
+        int lo_c = -1, hi_c = 0, lim = 0;                        // candidates 16 * c: c <= lo_c hold, c >= hi_c do not
+        if (sgi > 0 && sgi < S) { const int xs = s_x[sgi]; lim = way[xs] - warm; hi_c = xs / 16; }
+        for (int round = 0; round < 8; ++round) {                // (16^3 = 4096 candidates cover 35 000 rows; the bound is slack)
+            const int span = hi_c - lo_c - 1;                    // undecided candidates
+            const int step = (span + 15) / 16;                   // uniform over the 16 lanes of a segment
+            const int cand = lo_c + (li + 1) * step;
+            const bool test = sgi > 0 && sgi < S && span > 0 && cand < hi_c;
+            const bool holds = test && way[16 * cand] <= lim;
+            const unsigned long long bal = __ballot(holds);
+            const unsigned mine = (unsigned)(bal >> (16 * ((tid & 63) >> 4))) & 0xffffu;   // this segment's 16 answers: a prefix of ones
+            const int pt = __builtin_popcount(mine);
+            if (span > 0) {
+                const int nlo = pt > 0 ? lo_c + pt * step : lo_c;
+                const int nhi = pt < 16 ? min(hi_c, lo_c + (pt + 1) * step) : hi_c;
+                lo_c = nlo; hi_c = nhi;
+            }
+            if (__syncthreads_or(hi_c - lo_c - 1 > 0) == 0) break;
         }
-        s_xb[tid] = xb;
+        if (li == 0 && sgi < S) s_xb[sgi] = (sgi == 0 || lo_c < 0) ? 0 : 16 * lo_c;
     }
     __syncthreads();
     // cells of the rows [xb, xe): B each, less what the MSA's right edge cuts off the band (PW:1497) -- only the rows from
-    // the first one whose band reaches it, a suffix of the row (Way[] is increasing)
+    // the first one whose band reaches it, a suffix of the row (Way[] is increasing): found by all threads at once
     __shared__ int s_xr, s_grow[SEG_MAX + 1];
     if (tid == 0) {
-        int a = 0, b = L;                                     // first row x with max(0, way[x] - H) + B > W
-        while (a < b) { const int mid = (a + b) >> 1; if (max(0, way[mid] - H) + B > W) b = mid; else a = mid + 1; }
-        s_xr = a;
+        s_xr = L;
         int grow = 0;
         for (int s2 = 0; s2 <= S; ++s2) { s_grow[s2] = grow; if (s2 < S) grow += s_x[s2 + 1] - s_xb[s2]; }
     }
     __syncthreads();
+    {
+        // first row x with max(0, way[x] - H) + B > W: every thread probes one of 1024 evenly spaced rows, then the rows of
+        // the stretch in front of the first hit
+        const int stride = L / GATHER_NT + 1;
+        const int c = min(L - 1, tid * stride);
+        if (max(0, way[c] - H) + B > W) atomicMin(&s_xr, c);
+        __syncthreads();
+        const int hit = s_xr;                                    // a probed row that qualifies (or L): the first one lies in (hit - stride, hit]
+        __syncthreads();
+        const int x2 = hit - stride + 1 + tid;
+        if (tid < stride && x2 >= 0 && x2 < hit && max(0, way[x2] - H) + B > W) atomicMin(&s_xr, x2);
+        __syncthreads();
+    }
     const int xr = s_xr;
     for (int x = xr + tid; x < L; x += GATHER_NT) {
         const unsigned long long cut = (unsigned long long)(B - min(B, W - max(0, way[x] - H)));
