@@ -164,6 +164,7 @@ struct JobBufs {
     int force64;                   // test hook: every job takes the 64-bit fill
     int evcap;                     // commits with more structural events than this renumber by a pass over the width (test hook; <= EVCAP)
     int gate_v2;                   // k_fill_v2 launched behind k_fill_v3: it runs only while Hdr::fallback > 0
+    int trace_blk;                 // this batch's traceback is k_trace_blk's (its chunk words carry the 'up' moves of every 64 rows)
     int v2_follows, f64_follows;   // this batch's launches include the stand-in k_fill_v2 / the 64-bit k_fill64 (the host adds them when the
                                    // header it last saw says they are wanted; a job that wanted one in a batch without it is repeated)
     int stall_test;                // test hook: job 0 of this k_fill_v3 launch pretends its neighbour never answers
@@ -2837,7 +2838,7 @@ __device__ __forceinline__ int row_symbol(const uint8_t *mk, int y, int lo, int 
 }
 
 #define EVCAP 1024                  // structural events (columns opened / emptied) of one commit handled without a pass over the width
-struct CommitEv { int key[EVCAP], dl[EVCAP], skey[EVCAP], scum[EVCAP], seg_lo[EVCAP + 1], seg_sh[EVCAP + 1], seg_pre[EVCAP + 2]; };
+struct CommitEv { int key[EVCAP], dl[EVCAP], skey[EVCAP], scum[EVCAP], seg_lo[EVCAP + 1], seg_sh[EVCAP + 1], seg_pre[EVCAP + 2], cpre[COMMIT_NT]; };
 
 __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_i, CommitEv *ev)
 {
@@ -2885,14 +2886,33 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
     //    marks of the new placement.  The tallies of the neighbour column y are read as the trace saw them: the row's old
     //    symbol taken out, the new one not yet put in.
     unsigned carry = 0;
+    // Which new column is a base's (idx: the number of columns opened by the bases before it)?  k_trace_blk has counted the
+    // 'up' moves of every 64 rows: a prefix over its chunks and a ballot inside the wave give idx without a block scan per
+    // 1024 bases; the other traceback kernels leave the scan to this loop.
+    const bool by_chunk = jb.trace_blk != 0 && ((L + 63) >> 6) <= COMMIT_NT;
+    if (by_chunk) {
+        const unsigned long long *hand = jb.gtr + (size_t)job * jb.trk;
+        const int nch = (L + 63) >> 6;
+        const unsigned mine = tid < nch ? (unsigned)((hand[tid] >> 41) & 0x7full) : 0u;
+        unsigned tot;
+        const unsigned incl = block_incl_add<COMMIT_NT>(mine, sh, tot);
+        ev->cpre[tid] = (int)(incl - mine);
+        __syncthreads();
+    }
     for (int base = 0; base < L; base += COMMIT_NT) {
         const int x = base + tid;
         const int c = (x < L) ? newcol[x] : 0;
         const unsigned ins = (x < L && (c & 1)) ? 1u : 0u;
-        unsigned tot;
-        const unsigned incl = block_incl_add<COMMIT_NT>(ins, sh, tot);
-        const int idx = (int)(carry + incl - ins);
-        carry += tot;
+        int idx;
+        if (by_chunk) {
+            const unsigned long long bal = __ballot(ins != 0u);
+            idx = ev->cpre[min(x, L - 1) >> 6] + __builtin_popcountll(bal & ((1ull << (tid & 63)) - 1ull));
+        } else {
+            unsigned tot;
+            const unsigned incl = block_incl_add<COMMIT_NT>(ins, sh, tot);
+            idx = (int)(carry + incl - ins);
+            carry += tot;
+        }
         if (x < L) {
             const int y = c >> 1;
             const int sloty = order[y];
@@ -4022,10 +4042,11 @@ static int enqueue_batch(pwr_ctx *c, Hdr *host_copy, unsigned host_seq)
     if (c->par_trace) {
         if (++c->trace_epoch >= (1u << 14)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * c->jb.trk * 8, c->stream)); c->trace_epoch = 1; }
         c->jb.trace_tag = c->trace_epoch;
-        if (c->par_trace == 2 && c->st.colcap < TB_MAXCOL) hipLaunchKernelGGL(k_trace_blk, dim3(n, (c->jb.Lmax / 64 + TB_W) / TB_W), dim3(TB_W * 64), 0, c->stream, c->st, c->jb);
+        c->jb.trace_blk = (c->par_trace == 2 && c->st.colcap < TB_MAXCOL) ? 1 : 0;
+        if (c->jb.trace_blk) hipLaunchKernelGGL(k_trace_blk, dim3(n, (c->jb.Lmax / 64 + TB_W) / TB_W), dim3(TB_W * 64), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
     }
-    else hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb);
+    else { c->jb.trace_blk = 0; hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb); }
     hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n, c->d_rowids, host_copy, host_seq);
     HIPC(hipGetLastError());
     return PWR_OK;
