@@ -1706,15 +1706,27 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
             // 64-row block whose band end lies beyond the strip's first column (or to the next block) in one step -- with
             // more macro-strips than the band is wide (NW * MS > B + MS) a wave spends whole laps here.
             const int y0s = lo + ms * MS;
-            const unsigned long long wm = __builtin_amdgcn_ballot_w64(min((int)(dca & 0xffffffu) + B, W) > y0s) >> (x & 63);
+            const int anf_l = (int)(dca & 0xffffffu);                             // lane = row of this 64-row block
+            const unsigned long long wm = __builtin_amdgcn_ballot_w64(min(anf_l + B, W) > y0s) >> (x & 63);
             const int xn = min(wm ? x + __builtin_ctzll(wm) : ((x >> 6) + 1) << 6, L);     // (> x: row x itself has no work)
             // (take the strip over at the group boundary before xn, see V4_EARLY_MASKS; the fast path starts it)
             int xs = xn;
             if (wm && xn < Lf) {
+                // A TEAR is a row whose band starts at or beyond the end of the band of the row above (the row's next base lies
+                // more than a bandwidth further right: a run of blanks between two of its segments).  No strip is taken over
+                // across one: the waves of the strips the band jumps over never run the rows in between, so nobody would hand
+                // anything over there -- the rows run ahead start at the last tear up to xn at the earliest (every wave applies
+                // the same rule, so a wave's rows ahead are always covered by its left neighbour's).  And a strip the band
+                // jumps over altogether in row xn is not started at all: the general path changes strips first.
+                const int anf_up = __builtin_amdgcn_update_dpp(0x3fffffff, anf_l, DPP_WAVE_SHR1, 0xF, 0xF, false);
+                const unsigned long long tears = __builtin_amdgcn_ballot_w64(anf_l >= min(anf_up + B, W)) >> (x & 63);   // bit i: row x + i
+                const unsigned long long tm = tears & (~0ull >> (63 - (xn - x))) & ~1ull;                              // rows (x, xn]
                 xs = max(x, xn & ~15);
+                if (tm) xs = max(xs, x + 63 - __builtin_clzll(tm));
                 if (xs < 1) xs = xn;
-                early_lo = xs; early_hi = xn;
-                first_pending = xs > 0 ? 1 : 0;
+                const int an = __builtin_amdgcn_readlane(anf_l, xn & 63);
+                if (ms < (an - lo) / MS) { xs = xn; first_pending = 0; }
+                else { early_lo = xs; early_hi = xn; first_pending = xs > 0 ? 1 : 0; }
             }
             DG_INC(dg_nowork, xs - x)
             if (xs > x) {

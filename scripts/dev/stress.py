@@ -1,0 +1,52 @@
+"""dev (GPU box): randomised parity sweep -- small simulated MSAs of random shape, random bandwidth / window / segment plan /
+traceback kernel / wave geometry, three rounds each, exported text and total score against the CPU oracle after every round.
+usage: stress.py [seconds] [seed]"""
+import sys, time, signal
+import numpy as np
+signal.signal(signal.SIGALRM, signal.SIG_DFL)        # a case that hangs ends the process; its parameters are the last line of the log
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from conftest import Oracle
+from repeatresolver_amd import datagen as dg
+from repeatresolver_amd.realigner import PWReAligner
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+oracle = Oracle(); lib = oracle.lib
+t_end = time.time() + budget
+n = bad = 0
+tot = {"seg_jobs": 0, "seg_fails": 0, "rows_ahead": 0, "rows_committed": 0, "rows_recomputed": 0}
+while time.time() < t_end:
+    cfg = dg.SimConfig(kind=str(rng.choice(["Tree", "Distributed", "EquiDistant"])), copies=int(rng.integers(2, 9)), coverage=int(rng.integers(3, 18)),
+                       difference=float(rng.choice([0.005, 0.01, 0.03])), repeat_len=int(rng.integers(400, 3500)), flank=int(rng.integers(100, 900)),
+                       length_scale=float(rng.choice([0.03, 0.06, 0.12, 0.25])), min_aligned=int(rng.integers(30, 120)), seed=int(rng.integers(1, 10**6)))
+    try:
+        rows = [bytes(r) for r in dg.build_msa(dg.simulate(cfg))]
+    except Exception as e:                       # (a configuration that yields no reads)
+        continue
+    if len(rows) < 3 or len(rows) * len(rows[0]) > 4_000_000:
+        continue
+    bw = int(rng.choice([2, 5, 8, 16, 33, 50, 120, 300, 1000, 1500]))
+    opts = dict(window=int(rng.choice([1, 2, 3, 8, 64])), seg_rows=int(rng.choice([0, 64, 128, 160, 256])), seg_max=int(rng.choice([4, 16, 64])),
+                warm_pct=int(rng.choice([20, 100, 190, 300])), ptrace=int(rng.choice([0, 1, 2, 2, 2])), waves=int(rng.choice([3, 4, 5, 5, 8, 9, 17])),
+                onewg=int(rng.choice([0, 0, 1])), seg_align=int(rng.choice([16, 32, 64])), slack=int(rng.choice([0, 8192])))
+    print("case", n, cfg, "bw", bw, opts, "rows", len(rows), "x", len(rows[0]), flush=True)
+    signal.alarm(120)
+    g = PWReAligner(rows, bandwidth=bw, **opts)
+    g.trim_ends()
+    h = oracle.create(rows, bw); lib.pwo_trim(h)
+    ok = True
+    for rnd in range(3):
+        g.realign_round(); lib.pwo_realign_round(h)
+        if g.total_score() != lib.pwo_total_score(h) or g.export_rows() != oracle.export(h):
+            ok = False; break
+    st = g.stats()
+    for k in tot: tot[k] += st[k]
+    if ok and st["cells_reference"] != lib.pwo_cells(h): ok = False
+    n += 1
+    if n % 10 == 0: print("...", n, "cases", bad, "mismatches", flush=True)
+    if not ok:
+        bad += 1
+        print("MISMATCH", cfg, "bw", bw, opts, "round", rnd, flush=True)
+    lib.pwo_destroy(h); g.close()
+    signal.alarm(0)
+print(f"{n} cases, {bad} mismatches; {tot}")

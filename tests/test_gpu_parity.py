@@ -37,7 +37,7 @@ STEP_CASES = [("toy_a_b1000", 1000, 2), ("toy_a_b50", 50, 2), ("tiny_b10", 10, 3
 def _row_by_row(name, bw, rounds, oracle, **opts):
     """Every single realignment: same Way, same entry column, same new placement, same MSA."""
     from repeatresolver_amd.realigner import PWReAligner
-    rows = split_rows(golden_input(name))
+    rows = name if isinstance(name, list) else split_rows(golden_input(name))
     force64 = opts.pop("force64", None)
     g = PWReAligner(rows, bandwidth=bw, **opts)
     if force64 is not None:

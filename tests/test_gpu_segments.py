@@ -161,3 +161,19 @@ def test_rows_committed_ahead_survive_a_regrow(oracle):
     assert st["rows_ahead"] > 0
     lib.pwo_destroy(h)
     g.close()
+
+
+@pytest.mark.parametrize("bw,opts", [(1500, {}), (1600, {}), (1500, {"seg_rows": 0}), (1500, {"seg_rows": 128, "warm_pct": 20}),
+                                     (1000, {"waves": 9}), (1000, {"waves": 17}), (700, {"waves": 3}), (1000, {"onewg": 1})],
+                         ids=["b1500", "b1600", "b1500_one_piece", "b1500_short_warmup", "b1000_w9", "b1000_w17", "b700_w3", "b1000_onewg"])
+def test_rows_that_jump_further_than_the_band(bw, opts, oracle):
+    """Found by scripts/dev/stress.py (in the round-2 library too): rows that still have a run of blanks between two of
+    their segments wider than the whole band -- consecutive DP rows whose bands do not overlap (PW:285-295 carries the row
+    minimum across).  With more macro-strips than the band is wide (bandwidths above 1024: 9 strips of 256 columns) a
+    k_fill_v3 wave that was idle used to take over a strip the band had already jumped past.  Wide bands on a short MSA
+    spread the rows out, so that the second round has such rows; every realignment of three rounds is compared."""
+    from repeatresolver_amd import datagen as dg
+    cfg = dg.SimConfig(kind="Tree", copies=5, coverage=14, difference=0.005, repeat_len=478, flank=676, length_scale=0.06,
+                       min_aligned=102, seed=30351)
+    rows = [bytes(r) for r in dg.build_msa(dg.simulate(cfg))]
+    _row_by_row(rows, bw, 3, oracle, window=1, **opts)
