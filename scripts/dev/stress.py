@@ -1,9 +1,23 @@
 """dev (GPU box): randomised parity sweep -- small simulated MSAs of random shape, random bandwidth / window / segment plan /
 traceback kernel / wave geometry, three rounds each, exported text and total score against the CPU oracle after every round.
 usage: stress.py [seconds] [seed]"""
-import sys, time, signal
+import sys, os, time, threading, subprocess, faulthandler, signal
 import numpy as np
-signal.signal(signal.SIGALRM, signal.SIG_DFL)        # a case that hangs ends the process; its parameters are the last line of the log
+
+
+def watchdog():
+    """a case that makes no progress: where is the process stuck?  (its parameters are the last "case" line of the log)"""
+    print("\n[watchdog] no progress for 45 s", flush=True)
+    for t in os.listdir("/proc/self/task"):
+        try:
+            st = open(f"/proc/self/task/{t}/stat").read().split()
+            print("   thread", t, "state", st[2], "wchan", open(f"/proc/self/task/{t}/wchan").read(), flush=True)
+        except Exception as e:
+            print("   thread", t, e, flush=True)
+    try:
+        print(subprocess.run(["rocm-smi", "--showuse"], capture_output=True, text=True, timeout=10).stdout, flush=True)
+    except Exception as e:
+        print("rocm-smi:", e, flush=True)
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from conftest import Oracle
 from repeatresolver_amd import datagen as dg
@@ -19,10 +33,15 @@ while time.time() < t_end:
     cfg = dg.SimConfig(kind=str(rng.choice(["Tree", "Distributed", "EquiDistant"])), copies=int(rng.integers(2, 9)), coverage=int(rng.integers(3, 18)),
                        difference=float(rng.choice([0.005, 0.01, 0.03])), repeat_len=int(rng.integers(400, 3500)), flank=int(rng.integers(100, 900)),
                        length_scale=float(rng.choice([0.03, 0.06, 0.12, 0.25])), min_aligned=int(rng.integers(30, 120)), seed=int(rng.integers(1, 10**6)))
+    # (the simulator mirrors the reference's coverage loop, which need not end when the flanks outweigh the repeat: bounded here)
+    signal.signal(signal.SIGALRM, lambda s, f: (_ for _ in ()).throw(TimeoutError()))
+    signal.alarm(10)
     try:
         rows = [bytes(r) for r in dg.build_msa(dg.simulate(cfg))]
-    except Exception as e:                       # (a configuration that yields no reads)
+    except Exception as e:                       # (a configuration that yields no reads, or never reaches its coverage)
         continue
+    finally:
+        signal.alarm(0)
     if len(rows) < 3 or len(rows) * len(rows[0]) > 4_000_000:
         continue
     bw = int(rng.choice([2, 5, 8, 16, 33, 50, 120, 300, 1000, 1500]))
@@ -30,15 +49,19 @@ while time.time() < t_end:
                 warm_pct=int(rng.choice([20, 100, 190, 300])), ptrace=int(rng.choice([0, 1, 2, 2, 2])), waves=int(rng.choice([3, 4, 5, 5, 8, 9, 17])),
                 onewg=int(rng.choice([0, 0, 1])), seg_align=int(rng.choice([16, 32, 64])), slack=int(rng.choice([0, 8192])))
     print("case", n, cfg, "bw", bw, opts, "rows", len(rows), "x", len(rows[0]), flush=True)
-    signal.alarm(120)
+    tm = threading.Timer(45, watchdog); tm.daemon = True; tm.start()
+    faulthandler.dump_traceback_later(70, exit=True)
     g = PWReAligner(rows, bandwidth=bw, **opts)
     g.trim_ends()
     h = oracle.create(rows, bw); lib.pwo_trim(h)
     ok = True
     for rnd in range(3):
-        g.realign_round(); lib.pwo_realign_round(h)
+        print(" gpu", end="", flush=True); g.realign_round()
+        print(" oracle", end="", flush=True); lib.pwo_realign_round(h)
+        print(" compare", end="", flush=True)
         if g.total_score() != lib.pwo_total_score(h) or g.export_rows() != oracle.export(h):
             ok = False; break
+    print(" done", flush=True)
     st = g.stats()
     for k in tot: tot[k] += st[k]
     if ok and st["cells_reference"] != lib.pwo_cells(h): ok = False
@@ -48,5 +71,5 @@ while time.time() < t_end:
         bad += 1
         print("MISMATCH", cfg, "bw", bw, opts, "round", rnd, flush=True)
     lib.pwo_destroy(h); g.close()
-    signal.alarm(0)
+    tm.cancel(); faulthandler.cancel_dump_traceback_later()
 print(f"{n} cases, {bad} mismatches; {tot}")
