@@ -87,6 +87,20 @@ int pwr_realign_round(pwr_ctx *ctx);
 /* A slab of that k-loop: rows k0 .. k0+n-1 in input order (a partial PW:1695 loop).  Calling it for consecutive
  * slabs that cover 0..rows-1 equals pwr_realign_round; speculation stays inside the slab. */
 int pwr_realign_rows(pwr_ctx *ctx, int k0, int n);
+/* The same slab with the work of every speculative batch split over `world` contexts, one per GPU of a node, each a
+ * replica built from the same text with the same options (SURVEY 8e "within one MSA": the rows of the k-loop window PW:1695
+ * are realigned side by side against the last committed state and committed in the reference's order; a replica fills and
+ * traces the jobs j of a batch with j % world == rank, and commits them all).  Per batch the caller all-gathers one record
+ * per job (RCCL over xGMI when the ranks are GPUs of a node; this library links no communication library):
+ *     pwr_split_begin(ctx, k0, n, rank, world);
+ *     do { pwr_split_stage(ctx, send); <all-gather send -> recv>; pwr_split_commit(ctx, recv, &left); } while (left > 0);
+ * send: slots_per_rank * slot_bytes of DEVICE memory (pwr_split_slot_bytes), recv: world times that, the ranks' parts in
+ * rank order.  "window" (set before the first device call) is the batch size, world <= window.  The MSA afterwards is the
+ * one pwr_realign_rows(k0, n) leaves on one GPU, on every replica. */
+int pwr_split_begin(pwr_ctx *ctx, int k0, int n, int rank, int world);
+int pwr_split_slot_bytes(pwr_ctx *ctx, size_t *slot_bytes, int *slots_per_rank);
+int pwr_split_stage(pwr_ctx *ctx, void *send_dev);
+int pwr_split_commit(pwr_ctx *ctx, const void *recv_dev, int *rows_left);
 /* The integer total that OverallScorePrint prints (PW:864-892, PW:933-963); compacts first. */
 int pwr_total_score(pwr_ctx *ctx, uint64_t *total);
 /* Tiefe / current Breite (PW:86-87). */
@@ -102,9 +116,10 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
  *   "waves"     waves per DP segment of the wave-pipeline fills: 5 (default, 4 columns per lane), 9, 8, 4, 3, or 17 with
  *               k_fill_v3 only; bandwidths above 1000 always use 9
  *   "onewg"     1 = the waves of a k_fill_v3 segment form ONE work-group and hand over through LDS (default 0: measured slower)
- *   "seg_rows", "seg_max", "warm_pct", "seg_align"
+ *   "seg_rows", "seg_max", "warm_pct", "seg_align", "src_start"
  *               k_fill_v3 fills a DP as up to seg_max (<= 64, default 64) segments of about seg_rows (default 160) rows side
- *               by side, each warmed up while the band moves by warm_pct (default 190) percent of the bandwidth, and CHECKS
+ *               by side, each warmed up while the band moves by warm_pct (default 190) percent of the bandwidth -- from the
+ *               column of the base before its first row alone (src_start 1, default) or from the free start of PW:265 (0) -- and CHECKS
  *               every segment's start; a row whose check fails is repeated with twice the warm-up, then in
  *               one piece (pwr_stats.seg_fails).  seg_rows 0 = always in one piece; seg_align (16, 32, 64): the segments' first rows are
  *               multiples of it
@@ -112,7 +127,7 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
  *               handing over top-down), 0 = k_trace_wp (one wave per job)
  *   "slack"     spare column capacity kept when the device arrays are (re)allocated
  *   "spec_len"  percent a speculative row may be longer than the first row of its batch (default 6)
- * "fill", "waves", "slack" and the "seg" options must be set before the first call that touches the device. */
+ * "fill", "waves", "slack", "src_start" and the "seg" options must be set before the first call that touches the device. */
 int pwr_set_option(pwr_ctx *ctx, const char *key, long value);
 int pwr_get_option(pwr_ctx *ctx, const char *key, long *value);
 int pwr_get_stats(pwr_ctx *ctx, pwr_stats *out);

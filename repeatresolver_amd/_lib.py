@@ -21,7 +21,7 @@ class PwrStats(ctypes.Structure):
 EXPORTS = ["pwr_create", "pwr_destroy", "pwr_trim_ends", "pwr_realign_row", "pwr_realign_round", "pwr_realign_rows",
            "pwr_total_score", "pwr_dims", "pwr_export_rows", "pwr_set_option", "pwr_get_option", "pwr_get_stats",
            "pwr_reset_stats", "pwr_strerror", "pwr_device_count", "pwr_read_msa_file",
-           "pwr_write_msa_file", "pwr_run_file"]
+           "pwr_write_msa_file", "pwr_run_file", "pwr_split_begin", "pwr_split_slot_bytes", "pwr_split_stage", "pwr_split_commit"]
 
 # every symbol include/pia.h declares (the InitialAligner)
 PIA_EXPORTS = ["pia_create", "pia_destroy", "pia_align", "pia_get_stats", "pia_set_option", "pia_get_timing", "pia_read_template", "pia_read_fasta",
@@ -70,6 +70,14 @@ def load():
     lib.pwr_strerror.argtypes = [ci]
     lib.pwr_device_count.restype = ci
     lib.pwr_device_count.argtypes = []
+    lib.pwr_split_begin.restype = ci
+    lib.pwr_split_begin.argtypes = [vp, ci, ci, ci, ci]
+    lib.pwr_split_slot_bytes.restype = ci
+    lib.pwr_split_slot_bytes.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ci)]
+    lib.pwr_split_stage.restype = ci
+    lib.pwr_split_stage.argtypes = [vp, vp]
+    lib.pwr_split_commit.restype = ci
+    lib.pwr_split_commit.argtypes = [vp, vp, ctypes.POINTER(ci)]
     lib.pwr_debug_last_job.restype = ci
     lib.pwr_debug_last_job.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci),
                                        ctypes.POINTER(ci), ctypes.POINTER(ci), ci]

@@ -65,6 +65,11 @@ struct Hdr {                       // lives in device memory, one per context
     int noseg_level;               // ... once: its next fill warms up twice as long; twice: it runs in one piece
     unsigned seq;                  // host copy only: which batch this copy of the header belongs to (written last)
     int need64;                    // > 0: a job needed the 64-bit fill lately; the host launches k_fill64 with the batches while this counts down
+    // How long a segment warms up is steered by how often the check fails (k_commit_chain): every segmented fill that passes
+    // takes warm_step columns off, every one that fails puts 20 back on -- the length settles where about one fill in twenty
+    // is repeated, which is where a longer warm-up for all costs as much as the repeats it saves (measured).
+    // Results never depend on it.  warm_step 0: fixed length (JobBufs::warm_cols).
+    int warm_cur, warm_lo, warm_hi, warm_step;
     unsigned long long dbg[32];    // phase timers of commit and trace (10 ns ticks), only written by builds with -DPWR_DIAG
 };
 #ifdef PWR_DIAG
@@ -154,6 +159,7 @@ struct JobBufs {
     SegDesc *seg;                  // [njobs][SEG_MAX] plan of the fill (plan_segments, with k_gather_c)
     unsigned *chk;                 // [njobs][SEG_MAX + 1][2][NC] scores of the row before segment s: [0] as s has them after its warm-up, [1] as s - 1 ends
     int seg_align;                 // own parts start at multiples of this (16, 32 or 64)
+    int src_start;                 // 1: a warm-up starts from the column of the base before it alone (k_fill_v3), 0: from the free start
     int smax, seg_rows, warm_cols; // at most smax segments per job, of about seg_rows own rows, warmed up over warm_cols columns of band movement
     int gstride;                   // rows per wave of a job's mailbox area
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
@@ -172,7 +178,12 @@ struct JobBufs {
     int njobs_launched;
     int Lmax, colcap, NC;
     size_t dirstride;
+    // One round split over the GPUs of a node (pwr_split_*): every rank holds the whole state and gathers every
+    // job of a batch, but fills and traces only the jobs j with j % split_world == split_rank; the others' placements arrive
+    // through the all-gather, and every rank commits all of them in row order.  split_world <= 1: everything is this rank's.
+    int split_rank, split_world;
 };
+#define NOT_MINE(JB, JOB) ((JB).split_world > 1 && (JOB) % (JB).split_world != (JB).split_rank)
 
 // ---------------------------------------------------------------------------------------------
 // wave / block primitives (gfx950: 64-wide waves, DPP row shifts and row broadcasts)
@@ -408,7 +419,10 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
         if (jb.seg_rows > 0 && level < 2) S = (L + jb.seg_rows / 2) / jb.seg_rows;
         S = max(1, min(S, min(jb.smax, L / 128)));
         s_S = S;
-        s_warm = level == 1 ? 2 * jb.warm_cols : jb.warm_cols;
+        // (a row whose check failed: the longest warm-up the steering allows, twice that if it was already there)
+        const Hdr *hd = st.hdr;
+        const bool steered = hd->warm_step > 0;
+        s_warm = level == 1 ? ((steered && hd->warm_cur < jb.warm_cols) ? jb.warm_cols : 2 * jb.warm_cols) : (steered ? hd->warm_cur : jb.warm_cols);
         m->nseg = S; m->segfail = 0;
     }
     if (tid < SEG_MAX) s_cells[tid] = 0;
@@ -697,7 +711,7 @@ __global__ __launch_bounds__(NW * 64) void k_fill_v2(DState st, JobBufs jb)   //
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
     if (jb.gate_v2 && st.hdr->fallback <= 0) return;                              // only the stand-in for k_fill_v3 here
-    if (!m->active || L <= 0 || !m->ok || m->wide) return;
+    if (!m->active || L <= 0 || !m->ok || m->wide || NOT_MINE(jb, job)) return;
     const unsigned long long t_clk0 = __builtin_amdgcn_s_memtime(), t_real0 = __builtin_amdgcn_s_memrealtime();
     for (int i = tid; i < 2 * (MBDUMP + NW * 64); i += NW * 64) mbQ[i] = 0;
     for (int i = tid; i < PTDUMP + NW * 64; i += NW * 64) ptQ[i] = 0;
@@ -1156,7 +1170,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
     const SegDesc *const sd = jb.seg + (size_t)job * SEG_MAX + (vjob % jb.smax);
     JobMeta *m = &jb.meta[job];
     if (st.hdr->fallback > 0 && jb.v2_follows) return;                            // k_fill_v2 stands in (after a stall)
-    if (!m->active || m->L <= 0 || !m->ok || m->wide || !sd->active) return;
+    if (!m->active || m->L <= 0 || !m->ok || m->wide || !sd->active || NOT_MINE(jb, job)) return;
     // The segment is a DP of its own on the rows [xb, xe) of the job: x below counts from xb, and everything indexed by DP
     // row is addressed from there.  Its first row starts free (PW:265) whether it is the row's first base or not; its last
     // row is the DP's last row (PW:1386, entry scan) only in the job's last segment.
@@ -1250,9 +1264,20 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
     V4_LOADS(ms, 0, ug, gg, ig, gleft)
     V4_LOADS(msn, 1, nu, ng, ni, gleftn)
 
+    // Where a warm-up starts.  Any row vector will do for "the scores above the segment's first row" -- whether the warm-up
+    // forgot it is checked (k_seg_check) --, but how soon it is forgotten depends on it.  The free start of PW:265 (every
+    // column 0) lets paths begin anywhere in the band for nothing, and they have to die out or leave the band before the rows
+    // are parallel to the true ones (about 1.5 bandwidths of band movement).  The true vector is a steep V around the cell
+    // the best path goes through, and the row's present placement is the best guess at that cell: so the warm-up starts from
+    // ONE cell, the column of the base before its first row (score 0, every other column unreachable) -- the cells right of
+    // it get their scores from the row's own scan, the cells left of it stay unreachable until the band has left them behind,
+    // which takes half a bandwidth (measured with the oracle's tallies: scripts/dev/start_vectors.py).  Not when that
+    // column lies left of the first row's band (a run of blanks in the row): then the free start it is.
+    const int src_prev = (seg_xb > 0 && jb.src_start) ? UNI(way[-1]) : -1;
+    const int src_c = src_prev >= max(0, UNI(way[0]) - H) ? src_prev : -1;
     unsigned Mprev[C], accA[C], accC[C];
 #pragma unroll
-    for (int i = 0; i < C; ++i) { Mprev[i] = 0; accA[i] = accC[i] = 0; }
+    for (int i = 0; i < C; ++i) { Mprev[i] = (src_c < 0 || lo + ms * MS + lc + i == src_c) ? 0u : PWR_INF; accA[i] = accC[i] = 0; }
     int gacc = -1, nacc = 0;
     int ran_prev = 0;
     int x = 0, blk = 0;
@@ -1786,7 +1811,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
             if (dead) break;
         }
         int Mleft = (int)PWR_INF;
-        if (x == 0) Mleft = 0;
+        if (x == 0) Mleft = (src_c < 0 || yq == src_c) ? 0 : (int)PWR_INF;
         else if (yq < a_prev) Mleft = (int)PWR_INF;                              // PW:276
         else if (needM) Mleft = (int)eMy;
         else Mleft = gleft + (int)eTx;                                           // PW:285-295
@@ -1915,7 +1940,7 @@ __global__ __launch_bounds__(256) void k_seg_check(DState st, JobBufs jb)
     __shared__ int s_min[4], s_max[4], s_bad;
     const int job = blockIdx.x, s = blockIdx.y + 1, tid = threadIdx.x;
     JobMeta *m = &jb.meta[job];
-    if (!m->active || m->L <= 0 || !m->ok || m->wide || m->abort || (st.hdr->fallback > 0 && jb.v2_follows)) return;
+    if (!m->active || m->L <= 0 || !m->ok || m->wide || m->abort || (st.hdr->fallback > 0 && jb.v2_follows) || NOT_MINE(jb, job)) return;
     if (s >= m->nseg) return;
     const SegDesc *sd = jb.seg + (size_t)job * SEG_MAX + s;
     const int xr = sd->xown - 1;                                                   // the row both segments have
@@ -1964,7 +1989,7 @@ __global__ __launch_bounds__(F64_NT) void k_fill64(DState st, JobBufs jb)
     const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     JobMeta *m = &jb.meta[job];
     const int L = m->L;
-    if (!m->active || L <= 0 || !m->ok || !m->wide) return;
+    if (!m->active || L <= 0 || !m->ok || !m->wide || NOT_MINE(jb, job)) return;
     const int lo = m->lo, hi = m->hi, W = m->W, B = st.B, H = st.H, RS = jb.NC;
     const int n = hi - lo + 1;
     const int *way = jb.way + (size_t)job * jb.Lmax;
@@ -2126,7 +2151,7 @@ __global__ __launch_bounds__(64) void k_trace_wp(DState st, JobBufs jb)
     const int job = blockIdx.x, lane = threadIdx.x;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
+    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows) || NOT_MINE(jb, job)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -2294,7 +2319,7 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
     const unsigned ttag = jb.trace_tag;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
+    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows) || NOT_MINE(jb, job)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
     const int W = UNI(m->W), B = st.B, H = st.H, RS = jb.NC, lo = UNI(m->lo);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const uint32_t *dirs = jb.dirs + (size_t)job * jb.dirstride;
@@ -2550,7 +2575,7 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
     const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
+    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows) || NOT_MINE(jb, job)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
     const int nch = (L + 63) >> 6;
     // the top chunks first: they are the ones everybody else waits for
     const int c = nch - 1 - UNI((int)blockIdx.y * TB_W + (tid >> 6));
@@ -3291,7 +3316,10 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
             if (m->segfail) {
                 // a segment of its fill had not forgotten its start when its own rows began (k_seg_check): the row is
                 // realigned again, its fill in one piece
-                if (threadIdx.x == 0) { h->seg_fails += 1; h->noseg_level = h->noseg_row == m->k ? h->noseg_level + 1 : 1; h->noseg_row = m->k; }
+                if (threadIdx.x == 0) {
+                    h->seg_fails += 1; h->noseg_level = h->noseg_row == m->k ? h->noseg_level + 1 : 1; h->noseg_row = m->k;
+                    if (h->noseg_level == 1) h->warm_cur = min(h->warm_hi, h->warm_cur + 20 * h->warm_step);
+                }
                 stopped = true;
                 continue;
             }
@@ -3319,7 +3347,10 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
                 continue;
             }
             commit_job(st, jb, j, sh, s_i, &evs);
-            if (threadIdx.x == 0 && h->noseg_row == m->k) { h->noseg_row = -1; h->noseg_level = 0; }
+            if (threadIdx.x == 0) {
+                if (h->noseg_row == m->k) { h->noseg_row = -1; h->noseg_level = 0; }
+                else if (m->nseg > 1) h->warm_cur = max(h->warm_lo, h->warm_cur - h->warm_step);
+            }
             live_done += 1;
             if (nskip > 0) ahead_n += 1;
             if (m->wide && threadIdx.x == 0) h->rows_wide += 1;
@@ -3362,6 +3393,66 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
     __threadfence();
     __syncthreads();
     publish_header(h, host_copy, host_seq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One round split over several GPUs (pwr_split_*): what a rank's fills and tracebacks produced travels as one fixed-size
+// record per job -- the job's JobMeta, its new placement newcol[Lmax], the chunk words of the traceback gtr[trk] (the commit
+// reads the 'up' moves of every 64 rows from them) --, is all-gathered by the caller, and is put into the job slots of the
+// ranks that did not compute it.  Everything else the commit reads (Way, the old marks, the interval, the version the inputs
+// were gathered at) every rank has made itself, from its own replica of the state, with the same gather.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ static inline size_t split_slot_bytes(int Lmax, int trk)
+{
+    return (sizeof(JobMeta) + (size_t)Lmax * 4 + (size_t)trk * 8 + 15) & ~(size_t)15;
+}
+
+__global__ __launch_bounds__(256) void k_split_export(JobBufs jb, int njobs, unsigned char *out)
+{
+    const int job = blockIdx.x, tid = threadIdx.x;
+    if (job >= njobs || NOT_MINE(jb, job)) return;
+    unsigned char *slot = out + (size_t)(job / jb.split_world) * split_slot_bytes(jb.Lmax, jb.trk);
+    const JobMeta *m = &jb.meta[job];
+    if (tid < (int)(sizeof(JobMeta) / 4)) reinterpret_cast<int *>(slot)[tid] = reinterpret_cast<const int *>(m)[tid];
+    if (!m->active || m->L <= 0) return;
+    int *nc = reinterpret_cast<int *>(slot + sizeof(JobMeta));
+    const int *src = jb.newcol + (size_t)job * jb.Lmax;
+    for (int x = tid; x < m->L; x += 256) nc[x] = src[x];
+    unsigned long long *gt = reinterpret_cast<unsigned long long *>(slot + sizeof(JobMeta) + (size_t)jb.Lmax * 4);
+    const unsigned long long *gs = jb.gtr + (size_t)job * jb.trk;
+    const int nch = min(jb.trk, (m->L + 63) >> 6);
+    for (int i = tid; i < nch; i += 256) gt[i] = gs[i];
+}
+
+__global__ __launch_bounds__(256) void k_split_import(DState st, JobBufs jb, int njobs, const unsigned char *in)
+{
+    const int job = blockIdx.x, tid = threadIdx.x;
+    if (job >= njobs || !NOT_MINE(jb, job)) return;
+    const int slots_per_rank = (njobs + jb.split_world - 1) / jb.split_world;
+    const unsigned char *slot = in + ((size_t)(job % jb.split_world) * slots_per_rank + (size_t)(job / jb.split_world)) * split_slot_bytes(jb.Lmax, jb.trk);
+    const JobMeta *src = reinterpret_cast<const JobMeta *>(slot);
+    JobMeta *m = &jb.meta[job];
+    // the replicas must agree on what the job is: same row, same length, gathered from the same version of the state
+    if (src->active != m->active || (m->active && (src->k != m->k || src->L != m->L || src->ver != m->ver || src->lo != m->lo || src->hi != m->hi))) {
+        if (tid == 0) atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL);
+        return;
+    }
+    if (!m->active || m->L <= 0) return;
+    const int L = m->L;
+    __syncthreads();
+    if (tid == 0) {
+        // what the owner's fill and traceback wrote (everything else is this rank's own gather)
+        m->entry = src->entry; m->ok = src->ok; m->nnew = src->nnew; m->abort = src->abort; m->changed = src->changed;
+        m->segfail = src->segfail; m->nseg = src->nseg; m->clk = src->clk; m->rclk = src->rclk; m->rounds = src->rounds;
+        if (!src->ok) atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL);               // (the owner's traceback found "Stuff gone wrong")
+    }
+    const int *nc = reinterpret_cast<const int *>(slot + sizeof(JobMeta));
+    int *dst = jb.newcol + (size_t)job * jb.Lmax;
+    for (int x = tid; x < L; x += 256) dst[x] = nc[x];
+    const unsigned long long *gt = reinterpret_cast<const unsigned long long *>(slot + sizeof(JobMeta) + (size_t)jb.Lmax * 4);
+    unsigned long long *gd = jb.gtr + (size_t)job * jb.trk;
+    const int nch = min(jb.trk, (L + 63) >> 6);
+    for (int i = tid; i < nch; i += 256) gd[i] = gt[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3466,7 +3557,12 @@ struct pwr_ctx {
     int seg_rows = 160;                   // k_fill_v3: a DP is filled in segments of about this many rows, side by side (0: in one piece)
     int seg_align = 16;                   // ... whose own parts start at multiples of this many rows (16 / 32 / 64)
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
-    int warm_pct = 190;                   // ... each warmed up while the band moves by this many percent of the bandwidth
+    int split_rank = 0, split_world = 1;  // pwr_split_*: this context is replica split_rank of split_world (one per GPU)
+    int split_k0 = 0, split_kend = 0;     // ... rows of the slab in progress
+    int src_start = 1;                    // ... from the column of the base before the warm-up's first row alone (0: from the free start)
+    int warm_pct = 190;                   // ... each warmed up while the band moves by this many percent of the bandwidth -- at most: with
+    int warm_adapt = 1;                   // "warm_adapt" (and src_start) the length is steered between warm_min_pct and warm_pct by the
+    int warm_min_pct = 100;               // failures of the check (Hdr::warm_cur)
     // stats
     pwr_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -3673,6 +3769,8 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
     jb.seg_align = c->seg_align;
     jb.seg_rows = c->fill_mode == 4 ? c->seg_rows : 0;
+    jb.src_start = c->src_start;
+    jb.split_rank = c->split_rank; jb.split_world = c->split_world;
     jb.warm_cols = (int)std::min<long long>((long long)c->B * c->warm_pct / 100 + 2, 1 << 20);
     jb.gstride = jb.Lmax + jb.smax * (2 * jb.warm_cols + 64);          // (a row whose check failed warms up twice as long)
     if ((rc = dmalloc(c, &jb.seg, (size_t)njobs * SEG_MAX))) return rc;
@@ -3815,6 +3913,13 @@ static int upload(pwr_ctx *c)
     int rc;
     Hdr hdr{};
     hdr.W = W; hdr.nslots = W; hdr.nfree = 0; hdr.cur = 0; hdr.agree = 0; hdr.noseg_row = -1;
+    {
+        const long long hi = std::min<long long>((long long)c->B * c->warm_pct / 100 + 2, 1 << 20);
+        const long long lo = std::min<long long>(hi, (long long)c->B * c->warm_min_pct / 100 + 2);
+        hdr.warm_hi = (int)hi; hdr.warm_lo = (int)lo;
+        hdr.warm_cur = (int)std::max(lo, std::min(hi, (long long)c->B * 140 / 100));
+        hdr.warm_step = (c->warm_adapt && c->src_start) ? std::max(1, c->B / 200) : 0;
+    }
     long long *d_rowoff; int *d_rowlen; uint8_t *d_seq;
     if ((rc = dmalloc(c, &st.hdr, 1))) return rc;
     if ((rc = dmalloc(c, &d_rowoff, T + 1))) return rc;
@@ -4041,7 +4146,7 @@ static int check_status(pwr_ctx *c)
 // One speculative batch, enqueued without waiting: the rows rowids[next_row ...] (Hdr, at most `window` of them) are
 // gathered from the committed state, filled and traced side by side, then committed in row order by one work-group that stops
 // at the first row whose inputs an earlier commit of this batch has changed, moves next_row on and sizes the next batch.
-static int enqueue_batch(pwr_ctx *c, Hdr *host_copy, unsigned host_seq)
+static int enqueue_front(pwr_ctx *c)
 {
     const int n = c->window;
     int rc;
@@ -4059,12 +4164,41 @@ static int enqueue_batch(pwr_ctx *c, Hdr *host_copy, unsigned host_seq)
         else hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
     }
     else { c->jb.trace_blk = 0; hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb); }
-    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n, c->d_rowids, host_copy, host_seq);
+    HIPC(hipGetLastError());
+    return PWR_OK;
+}
+
+static int enqueue_batch(pwr_ctx *c, Hdr *host_copy, unsigned host_seq)
+{
+    int rc = enqueue_front(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, c->window, c->d_rowids, host_copy, host_seq);
     HIPC(hipGetLastError());
     return PWR_OK;
 }
 
 #define PWR_INFLIGHT 3             // batches enqueued beyond the last one whose outcome the host has seen
+
+// Start a slab: rows [k0, k0 + n), first batch sized like the host did before (the running mean carries over).  (After a
+// regrow a slab goes on where it stood instead: the device's row pointer and its mask of rows already committed ahead of
+// order stay as they are -- each row is realigned once per round, PW:1695.)
+static int slab_init(pwr_ctx *c, int k0, int n)
+{
+    const int kend = k0 + n;
+    int nb = (int)(c->batch_ema + 2.6);
+    nb = std::max(1, std::min(nb, std::min(c->window, n)));
+    for (int j = 1; j < nb; ++j)
+        if (c->rowlen[k0 + j] > c->rowlen[k0] + (int)((long long)c->rowlen[k0] * c->spec_len / 100) + 64) { nb = j; break; }
+    const float ema0 = (float)c->batch_ema;
+    struct { int next_row, row_end, nb, need_grow, window; } init = {k0, kend, nb, 0, c->window};
+    static_assert(sizeof(init) == offsetof(Hdr, fallback) - offsetof(Hdr, next_row), "slab fields of Hdr");
+    HIPC(hipMemcpyAsync(&c->st.hdr->ema, &ema0, sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemcpyAsync(&c->st.hdr->speclen, &c->spec_len, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemcpyAsync(&c->st.hdr->next_row, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemsetAsync(&c->st.hdr->ahead, 0, sizeof(unsigned long long), c->stream));
+    HIPC(hipStreamSynchronize(c->stream));                                     // (init lives on the stack)
+    return PWR_OK;
+}
 
 // Rows k0 .. k0+n-1 in input order (a slab of the k loop, PW:1695-1737), speculative batches inside the slab only.  The
 // device sequences the rows itself (Hdr::next_row); the host keeps PWR_INFLIGHT batches queued and looks at a copy of the
@@ -4081,24 +4215,9 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
     Hdr *ring = static_cast<Hdr *>(c->h_ring);
     unsigned seqs[PWR_INFLIGHT] = {};
     const int kend = k0 + n;
-    if (!resume) {
-        // start the slab: rows [k0, kend), first batch sized like the host did before (the running mean carries over).
-        // (After a regrow the slab goes on where it stood: the device's row pointer and its mask of rows already committed
-        // ahead of order stay as they are -- each row is realigned once per round, PW:1695.)
-        int nb = (int)(c->batch_ema + 2.6);
-        nb = std::max(1, std::min(nb, std::min(c->window, n)));
-        for (int j = 1; j < nb; ++j)
-            if (c->rowlen[k0 + j] > c->rowlen[k0] + (int)((long long)c->rowlen[k0] * c->spec_len / 100) + 64) { nb = j; break; }
-        const float ema0 = (float)c->batch_ema;
-        struct { int next_row, row_end, nb, need_grow, window; } init = {k0, kend, nb, 0, c->window};
-        static_assert(sizeof(init) == offsetof(Hdr, fallback) - offsetof(Hdr, next_row), "slab fields of Hdr");
-        HIPC(hipMemcpyAsync(&c->st.hdr->ema, &ema0, sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIPC(hipMemcpyAsync(&c->st.hdr->speclen, &c->spec_len, sizeof(int), hipMemcpyHostToDevice, c->stream));
-        HIPC(hipMemcpyAsync(&c->st.hdr->next_row, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
-        HIPC(hipMemsetAsync(&c->st.hdr->ahead, 0, sizeof(unsigned long long), c->stream));
-        HIPC(hipStreamSynchronize(c->stream));                                 // (init lives on the stack)
-    }
     int rc;
+    c->split_rank = 0; c->split_world = 1; c->jb.split_rank = 0; c->jb.split_world = 1;   // (every job of a batch is this context's)
+    if (!resume && (rc = slab_init(c, k0, n))) return rc;
     long long issued = 0, looked = 0;                                          // batches enqueued / batches whose outcome the host has seen
     long long most = n;                                                        // every batch with rows left commits at least one ...
     while (true) {
@@ -4174,6 +4293,76 @@ extern "C" int pwr_realign_round(pwr_ctx *c)
     int rc = ensure_device(c);
     if (rc) return rc;
     return realign_range(c, 0, c->T);                                          // PW:1695: rows in input order
+}
+
+// ---------------------------------------------------------------------------------------------
+// One round split over the GPUs of a node ("within one MSA").  Every rank is a replica: it holds
+// the whole state, gathers every job of a batch and commits every job in row order -- so the replicas stay identical
+// without any state ever crossing a link --, but it FILLS and TRACES only its share of the batch (job j belongs to rank
+// j % world).  What crosses xGMI per batch is one record per job (new placement + a few words, pwr_split_slot_bytes):
+//     pwr_split_begin(ctx, k0, n, rank, world)
+//     do { pwr_split_stage(ctx, send);  all_gather(recv, send);  pwr_split_commit(ctx, recv, &left); } while (left > 0);
+// `send` = slots_per_rank * slot_bytes of DEVICE memory, `recv` = world times that, ranks in order (what RCCL's
+// all-gather produces).  The collective is the caller's (torch.distributed / RCCL): this library links no communication
+// library.  The results are those of pwr_realign_rows(k0, n) on one GPU, bit for bit.
+// ---------------------------------------------------------------------------------------------
+extern "C" int pwr_split_begin(pwr_ctx *c, int k0, int n, int rank, int world)
+{
+    if (!c || k0 < 0 || n < 0 || k0 > c->T || n > c->T - k0 || world < 1 || rank < 0 || rank >= world) return PWR_ERR_ARG;
+    int rc = ensure_device(c);
+    if (rc) return rc;
+    c->split_rank = rank; c->split_world = world;
+    c->jb.split_rank = rank; c->jb.split_world = world;
+    c->split_k0 = k0; c->split_kend = k0 + n;
+    if (n == 0) return PWR_OK;
+    return slab_init(c, k0, n);
+}
+
+extern "C" int pwr_split_slot_bytes(pwr_ctx *c, size_t *slot_bytes, int *slots_per_rank)
+{
+    if (!c || !slot_bytes || !slots_per_rank) return PWR_ERR_ARG;
+    int rc = ensure_device(c);
+    if (rc) return rc;
+    *slot_bytes = split_slot_bytes(c->jb.Lmax, c->jb.trk);
+    *slots_per_rank = (c->window + c->split_world - 1) / c->split_world;
+    return PWR_OK;
+}
+
+extern "C" int pwr_split_stage(pwr_ctx *c, void *send_dev)
+{
+    if (!c || !send_dev || !c->on_device) return PWR_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    int rc = enqueue_front(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_split_export, dim3(c->window), dim3(256), 0, c->stream, c->jb, c->window, static_cast<unsigned char *>(send_dev));
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->stream));                                     // the caller's collective runs on a stream of its own
+    return PWR_OK;
+}
+
+extern "C" int pwr_split_commit(pwr_ctx *c, const void *recv_dev, int *rows_left)
+{
+    if (!c || !recv_dev || !rows_left || !c->on_device) return PWR_ERR_ARG;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    if (c->split_world > 1)
+        hipLaunchKernelGGL(k_split_import, dim3(c->window), dim3(256), 0, c->stream, c->st, c->jb, c->window, static_cast<const unsigned char *>(recv_dev));
+    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, c->window, c->d_rowids, static_cast<Hdr *>(nullptr), 0u);
+    HIPC(hipGetLastError());
+    Hdr h;
+    int rc = read_hdr(c, &h);                                                  // (waits for the stream)
+    if (rc) return rc;
+    c->seen_fallback = h.fallback; c->seen_need64 = h.need64;
+    c->batch_ema = h.ema;
+    stats_from_hdr(c, h);
+    if (h.status) return h.status;
+    if (h.need_grow) {
+        // every replica finds the same shortage in the same batch and regrows alike; the slab goes on where it stands
+        long long growth = 0;
+        for (int j = 0; j < c->window && h.next_row + j < c->split_kend; ++j) growth += c->rowlen[h.next_row + j];
+        if ((rc = grow_state(c, growth))) return rc;
+    }
+    *rows_left = std::max(0, h.row_end - h.next_row);
+    return PWR_OK;
 }
 
 extern "C" int pwr_total_score(pwr_ctx *c, uint64_t *total)
@@ -4287,6 +4476,9 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "seg_rows")) { if (c->on_device || value < 0 || value > 1000000) return PWR_ERR_ARG; c->seg_rows = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_align")) { if (c->on_device || (value != 16 && value != 32 && value != 64)) return PWR_ERR_ARG; c->seg_align = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
+    if (!strcmp(key, "src_start")) { if (c->on_device || value < 0 || value > 1) return PWR_ERR_ARG; c->src_start = (int)value; return PWR_OK; }
+    if (!strcmp(key, "warm_adapt")) { if (c->on_device || value < 0 || value > 1) return PWR_ERR_ARG; c->warm_adapt = (int)value; return PWR_OK; }
+    if (!strcmp(key, "warm_min_pct")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->warm_min_pct = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_pct")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->warm_pct = (int)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9 && value != 17)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
     return PWR_ERR_ARG;
@@ -4307,6 +4499,13 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "seg_rows")) *value = c->seg_rows;
     else if (!strcmp(key, "seg_max")) *value = c->seg_max;
     else if (!strcmp(key, "warm_pct")) *value = c->warm_pct;
+    else if (!strcmp(key, "src_start")) *value = c->src_start;
+    else if (!strcmp(key, "warm_adapt")) *value = c->warm_adapt;
+    else if (!strcmp(key, "warm_now")) {                                      // percent of the bandwidth a warm-up covers right now
+        if (!c->on_device) *value = c->warm_pct;
+        else { Hdr h; int rc = read_hdr(c, &h); if (rc) return rc; *value = h.warm_step > 0 ? (long)(((long long)h.warm_cur * 100 + c->B / 2) / c->B) : c->warm_pct; }
+    }
+    else if (!strcmp(key, "warm_min_pct")) *value = c->warm_min_pct;
     else return PWR_ERR_ARG;
     return PWR_OK;
 }

@@ -1,0 +1,77 @@
+"""One realignment round of ONE MSA split over the GPUs of a node (SURVEY 8e "within one MSA"; north star: "within a
+round non-overlapping sequence realignments are partitioned across the GPUs with RCCL ... all-gather").
+
+One process per GPU, each holding a replica of the whole MSA state (built from the same text with the same options).
+The k loop of PW_ReAligner.c:1695 advances in speculative batches as on one GPU: the next `window` rows are
+gathered from the last committed state; rank r FILLS and TRACES the jobs j of the batch with j % world == r; the new
+placements -- one fixed-size record per job, a few tens of KB -- are all-gathered (RCCL over xGMI when the group is
+`nccl`); then every rank commits ALL jobs in row order with the same validation, so the replicas stay identical and no
+tally ever has to be sent: the "broadcast of the updated column tallies" is each replica applying the same delta.
+The result is bit-identical to PWReAligner.realign_rows on one GPU (and to the reference).
+
+All device work is libpwr.so (include/pwr.h, pwr_split_*); this module only owns the collective."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class SplitRound:
+    """Buffers and the per-batch loop for one PWReAligner replica of a process group."""
+
+    def __init__(self, realigner, group=None, device=None):
+        self.g = realigner
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if device is None:
+            device = torch.cuda.current_device()
+        self.dev = torch.device("cuda", device)
+        self.nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        self.send = self.recv = None
+        self.batches = 0
+        self.bytes_gathered = 0
+
+    def _buffers(self):
+        slot, per_rank = self.g.split_slot_bytes()
+        n = slot * per_rank
+        if self.send is None or self.send.numel() != n:
+            self.send = torch.zeros(n, dtype=torch.uint8, device=self.dev)
+            self.recv = torch.zeros(n * self.world, dtype=torch.uint8, device=self.dev)
+            if not self.nccl and self.world > 1:
+                self.h_send = torch.zeros(n, dtype=torch.uint8).pin_memory()
+                self.h_recv = torch.zeros(n * self.world, dtype=torch.uint8).pin_memory()
+
+    def _all_gather(self):
+        if self.nccl:
+            dist.all_gather_into_tensor(self.recv, self.send, group=self.group)      # RCCL (over xGMI between the GPUs of a node)
+        elif self.world == 1:
+            self.recv.copy_(self.send)
+        else:
+            # rehearsal backends (gloo): through pinned host memory
+            self.h_send.copy_(self.send)
+            parts = list(self.h_recv.chunk(self.world))
+            dist.all_gather(parts, self.h_send, group=self.group)
+            self.recv.copy_(self.h_recv)
+        torch.cuda.synchronize(self.dev)           # the commit runs on the context's own stream
+        self.bytes_gathered += self.recv.numel()
+
+    def realign_rows(self, k0, n):
+        """Rows k0 .. k0+n-1 of the round, in the reference's order; collective: every rank of the group calls it."""
+        self.g.split_begin(k0, n, self.rank, self.world)
+        if n == 0:
+            return
+        self._buffers()
+        left = n
+        budget = 4 * n + 256                       # every batch commits at least its first row, bar the rare repeat (stall, failed segment check)
+        while left > 0:
+            if budget == 0:
+                raise RuntimeError("split round: no progress")
+            budget -= 1
+            self.g.split_stage(self.send.data_ptr())
+            self._all_gather()
+            left = self.g.split_commit(self.recv.data_ptr())
+            self.batches += 1
+
+    def realign_round(self):
+        self.realign_rows(0, self.g.T)

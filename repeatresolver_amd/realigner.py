@@ -87,6 +87,23 @@ class PWReAligner:
     def realign_rows(self, k0, n):          # rows k0..k0+n-1 of that loop (a slab of PW_ReAligner.c:1695)
         _check(self._lib.pwr_realign_rows(self._h, k0, n), "pwr_realign_rows")
 
+    # ---- a slab with every batch's fills split over the GPUs of a node (include/pwr.h pwr_split_*; driver: intra_round.py)
+    def split_begin(self, k0, n, rank, world):
+        _check(self._lib.pwr_split_begin(self._h, k0, n, rank, world), "pwr_split_begin")
+
+    def split_slot_bytes(self):
+        sb, spr = ctypes.c_size_t(), ctypes.c_int()
+        _check(self._lib.pwr_split_slot_bytes(self._h, ctypes.byref(sb), ctypes.byref(spr)), "pwr_split_slot_bytes")
+        return sb.value, spr.value
+
+    def split_stage(self, send_ptr):         # send_ptr: device address (int) of slots_per_rank * slot_bytes bytes
+        _check(self._lib.pwr_split_stage(self._h, ctypes.c_void_p(send_ptr)), "pwr_split_stage")
+
+    def split_commit(self, recv_ptr) -> int:  # recv_ptr: device address of the all-gathered records; returns rows left in the slab
+        left = ctypes.c_int()
+        _check(self._lib.pwr_split_commit(self._h, ctypes.c_void_p(recv_ptr), ctypes.byref(left)), "pwr_split_commit")
+        return left.value
+
     def total_score(self) -> int:            # OverallScorePrint, PW_ReAligner.c:933-963
         v = ctypes.c_uint64()
         _check(self._lib.pwr_total_score(self._h, ctypes.byref(v)), "pwr_total_score")

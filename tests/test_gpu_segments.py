@@ -14,11 +14,45 @@ SEG_CASES = [("toy_b_b1000", 1000, 1), ("toy_a_b1000", 1000, 2), ("toy_a_b50", 5
              ("deep_b200", 200, 1), ("holes_b300", 300, 2)]
 
 
-@pytest.mark.parametrize("seg_rows,warm_pct", [(128, 200), (64, 300), (256, 150)])
+@pytest.mark.parametrize("seg_rows,warm_pct,src_start", [(128, 200, 1), (64, 300, 0), (256, 150, 1), (128, 110, 1), (128, 200, 0)])
 @pytest.mark.parametrize("name,bw,rounds", SEG_CASES, ids=[c[0] for c in SEG_CASES])
-def test_segmented_fill_row_by_row(name, bw, rounds, seg_rows, warm_pct, oracle):
-    """Every realignment of the fixtures with their fills cut into small segments: same Way, entry column, placement, MSA."""
-    _row_by_row(name, bw, rounds, oracle, seg_rows=seg_rows, seg_max=64, warm_pct=warm_pct)
+def test_segmented_fill_row_by_row(name, bw, rounds, seg_rows, warm_pct, src_start, oracle):
+    """Every realignment of the fixtures with their fills cut into small segments: same Way, entry column, placement, MSA --
+    whether a warm-up starts from the column of the base before it alone (src_start 1, the default) or from the free start
+    of PW:265 (0), and with a warm-up of 1.1 bandwidths that only the former can get away with (what it cannot is caught
+    by the check and repeated)."""
+    _row_by_row(name, bw, rounds, oracle, seg_rows=seg_rows, seg_max=64, warm_pct=warm_pct, src_start=src_start)
+
+
+def test_steered_warm_up_settles_and_changes_nothing(oracle):
+    """The length of the warm-ups follows the failures of the check (Hdr::warm_cur: a step down per segmented fill that
+    passes, twenty up per failure, between warm_min_pct and warm_pct).  With the lower bound far too short it must come
+    down, run into failures, go up again -- and the MSA is the reference's whatever it does."""
+    from repeatresolver_amd.realigner import PWReAligner
+    rows = split_rows(golden_input("toy_b_b1000"))
+    lib = oracle.lib
+    res = {}
+    for adapt in (0, 1):
+        g = PWReAligner(rows, bandwidth=1000, window=2, seg_rows=128, seg_max=64, warm_pct=200, warm_min_pct=10, warm_adapt=adapt)
+        g.trim_ends()
+        h = oracle.create(rows, 1000)
+        lib.pwo_trim(h)
+        seen = set()
+        for rnd in range(2):
+            for k0 in range(0, len(rows), 8):
+                g.realign_rows(k0, min(8, len(rows) - k0))
+                seen.add(g.get_option("warm_now"))
+            lib.pwo_realign_round(h)
+            assert g.total_score() == lib.pwo_total_score(h)
+            assert g.export_rows() == oracle.export(h)
+        st = g.stats()
+        assert st["cells_reference"] == lib.pwo_cells(h)
+        res[adapt] = (st["seg_fails"], st["cells_computed"], seen)
+        lib.pwo_destroy(h)
+        g.close()
+    assert res[0][0] == 0 and res[0][2] == {200}, res[0]           # fixed: the full length, no failures
+    assert res[1][0] > 0 and min(res[1][2]) < 140 and len(res[1][2]) > 3, res[1]
+    assert res[1][1] < res[0][1]                                     # shorter warm-ups: fewer cells computed
 
 
 @pytest.mark.parametrize("onewg", [0, 1])
@@ -60,7 +94,7 @@ def test_cells_computed_count_the_warm_up_rows(oracle):
     rows = split_rows(golden_input("toy_b_b1000"))
     bw, H, sr, smax, wp = 1000, 500, 128, 64, 150
     warm_cols = bw * wp // 100 + 2
-    g = PWReAligner(rows, bandwidth=bw, window=1, seg_rows=sr, seg_max=smax, warm_pct=wp)
+    g = PWReAligner(rows, bandwidth=bw, window=1, seg_rows=sr, seg_max=smax, warm_pct=wp, warm_adapt=0)   # (a fixed warm-up: the plan below)
     g.trim_ends()
     h = oracle.create(rows, bw)
     lib = oracle.lib
