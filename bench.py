@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--slabs", type=int, default=8, help="steps per realignment round (a step = T/slabs consecutive rows)")
     ap.add_argument("--sections", type=int, default=6, help="N > 1: Window.py parts the MSA is cut into (configs[3]: 6)")
     ap.add_argument("--window", type=int, default=None)
+    ap.add_argument("--split", default="sections", choices=["sections", "rows"],
+                    help="N > 1: sections = configs[3], the MSA cut into Window.py sections dealt to the ranks (default); rows = the WHOLE MSA on every "
+                         "rank, every speculative batch of the round's k loop split over the ranks, placements all-gathered (intra_round.py)")
     ap.add_argument("--fill", type=int, default=None, help="DP fill kernel (see include/pwr.h)")
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--spec-len", type=int, default=None, help="percent a speculative row may be longer than its batch's first row")
@@ -155,9 +158,14 @@ def main():
     note(f"generated {T} rows x {W0} columns in {gen_s:.1f} s")
 
     # ---- the units this rank owns
-    if world == 1:
+    split_rows_mode = world > 1 and args.split == "rows"
+    if world == 1 or split_rows_mode:
         units = [("whole MSA", rows)]
         bounds = None
+        owned = [["whole MSA (replica)"] for _ in range(world)]
+        load = [sum(len(r) - r.count(b"-") - r.count(b" ") for r in rows)] * world if split_rows_mode else [0]
+        if split_rows_mode and args.window is None:
+            args.window = max(3, world)                 # a batch has a job for every rank
     else:
         bounds = window_boundaries(rows, parts=args.sections)                 # Window.py:41-60
         secs = slice_sections(rows, bounds)
@@ -184,9 +192,16 @@ def main():
         ctxs.append(g)
     note(f"resident in HBM, score {score0}")
 
+    splitters = []
+    if split_rows_mode:
+        from repeatresolver_amd.intra_round import SplitRound
+        splitters = [SplitRound(ctxs[0], device=dev)]
+
     def run_step(i):
         k0, k1 = slab_bounds(T, args.slabs, i)
-        if len(ctxs) == 1:
+        if splitters:
+            splitters[0].realign_rows(k0, k1 - k0)
+        elif len(ctxs) == 1:
             ctxs[0].realign_rows(k0, k1 - k0)
         elif ctxs:
             ths = [threading.Thread(target=g.realign_rows, args=(k0, k1 - k0)) for g in ctxs]   # the C calls release the GIL
@@ -228,7 +243,7 @@ def main():
             dist.all_gather(css, cs)
             per_rank = [{"rank": r, "seconds": float(ts[r].item()), "cells": float(css[r].item())} for r in range(world)]
             tmax = max(p["seconds"] for p in per_rank)
-            csum = sum(p["cells"] for p in per_rank)
+            csum = per_rank[0]["cells"] if split_rows_mode else sum(p["cells"] for p in per_rank)   # (replicas: every rank commits every row)
             for p_ in per_rank:                    # a scaling curve must explain itself: 6 sections on 8 ranks leave 2 ranks idle
                 p_["sections"] = owned[p_["rank"]]
                 p_["bases"] = load[p_["rank"]]
@@ -250,6 +265,11 @@ def main():
             wl = (f"{cfg.name} ({args.workload}: {cfg.kind}, {cfg.copies} copies, {cfg.coverage:g}x, {cfg.repeat_len} bp; reads simulated with "
                   f"DataSimulator.py's distributions, seed {cfg.seed}; {made}) -> {T} rows x {W0} columns, bandwidth {args.bandwidth}; one step = "
                   f"{args.slabs}th of a realignment round = {T // args.slabs} consecutive rows, steps continue through successive rounds")
+        elif split_rows_mode:
+            wl = (f"{cfg.name} as above ({T} rows x {W0} columns; {made}), the WHOLE MSA as a replica on each of {world} ranks; every speculative batch "
+                  f"of the k loop (window {args.window}) is split over the ranks -- rank r fills and traces the jobs j % {world} == r --, the new placements "
+                  f"are all-gathered ({splitters[0].bytes_gathered / max(1, splitters[0].batches):.0f} B per batch and rank, {splitters[0].batches} batches) and "
+                  f"every rank commits all of them; one step = {T // args.slabs} consecutive rows")
         else:
             wl = (f"{cfg.name} as above ({T} rows x {W0} columns; {made}) cut into {args.sections} Window.py sections {bounds}, sections dealt to "
                   f"{world} ranks by bases; one step = the next {T // args.slabs} rows of every section")

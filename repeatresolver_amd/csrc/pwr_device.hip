@@ -286,7 +286,7 @@ __device__ __forceinline__ const int *cur_order(const DState &st)
 //   w = max(S(y,5), S(y-1,5))  (PW:1507), or PWR_INF where PW:1505 forbids opening a column.
 // ---------------------------------------------------------------------------------------------
 #define GATHER_NT 1024
-#define GATHER_G 8                 // work-groups per job: the rows and the interval's columns are cut into that many shares
+#define GATHER_G 16                // work-groups per job: the rows and the interval's columns are cut into that many shares
 struct GatherPart { unsigned long long ucost, cells; unsigned sum4, maxS, lastcov, tag; };   // what a share contributes, tag = launch
 
 // the job's row: the job-th row from next_row on that was not committed ahead of order already; -1: no such job in this batch
@@ -2936,9 +2936,20 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         ev->cpre[tid] = (int)(incl - mine);
         __syncthreads();
     }
-    for (int base = 0; base < L; base += COMMIT_NT) {
+    // (four bases per thread and turn: their placements, then the slots of their columns, are loaded side by side -- the
+    // loop is a chain of dependent loads, and with one base per turn it cost ten round trips to memory per 10 000 bases)
+    for (int base4 = 0; base4 < L; base4 += 4 * COMMIT_NT) {
+      int c4[4], sl4[4], bs4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int x = base4 + u * COMMIT_NT + tid; c4[u] = (x < L) ? newcol[x] : 0; bs4[u] = (x < L) ? (int)st.seq[off + x] : 0; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int x = base4 + u * COMMIT_NT + tid; sl4[u] = (x < L) ? order[c4[u] >> 1] : 0; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int base = base4 + u * COMMIT_NT;
+        if (base >= L) break;
         const int x = base + tid;
-        const int c = (x < L) ? newcol[x] : 0;
+        const int c = c4[u];
         const unsigned ins = (x < L && (c & 1)) ? 1u : 0u;
         int idx;
         if (by_chunk) {
@@ -2952,10 +2963,10 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         }
         if (x < L) {
             const int y = c >> 1;
-            const int sloty = order[y];
+            const int sloty = sl4[u];
             if (ins) {
                 const int slot = (idx < take) ? st.freelist[nfree - 1 - idx] : nslots + (idx - take);
-                const int bs = st.seq[off + x];
+                const int bs = bs4[u];
                 const Tally ty = st.tally[sloty];
                 // (the row itself out of both counts; between two of its segments it is blank, and a segment's last column
                 // counts as an end -- rows read with interior blanks, until this commit)
@@ -2978,9 +2989,10 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
             } else {
                 aux[x] = sloty;
                 st.pos[off + x] = sloty;
-                mark2[y - lo] = (uint8_t)(st.seq[off + x] + 1);
+                mark2[y - lo] = (uint8_t)(bs4[u] + 1);
             }
         }
+      }
     }
     __syncthreads();
     PH_ADD(h, 2)
@@ -3009,23 +3021,38 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
         }
         __syncthreads();
         const int nchg = s_i[8];
-        for (int i = tid; i < nchg; i += COMMIT_NT) {
-            const int e_ = list[i];
-            const int y = e_ & 0xffffff, so = (e_ >> 24) & 15, sn = (e_ >> 28) & 15;
-            const int slot = order[y];
-            Tally *t = &st.tally[slot];
-            uint32_t w4 = 0;
+        // (four changed columns per thread and turn, every column is in the list once: entries, slots and tallies are
+        // loaded side by side)
+        for (int i4 = tid; i4 < nchg; i4 += 4 * COMMIT_NT) {
+            int e4[4], s4[4];
+            Tally t4[4];
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const uint32_t v = t->w[b] - ((so != 5 && b != so) ? 1u : 0u) + ((sn != 5 && b != sn) ? 1u : 0u);
-                t->w[b] = v;
-                if (b == 4) w4 = v;
-            }
-            st.colver[slot] = newver;
-            s_i[3] = 1;
-            if (w4 == 0) {
-                s_i[1] = 1; atomicMin(&s_i[4], y);
-                const int e = atomicAdd(&s_i[5], 1); if (e < EVCAP) { ev->key[e] = 2 * y; ev->dl[e] = -1; }              // column y loses its last base
+            for (int u = 0; u < 4; ++u) { const int i = i4 + u * COMMIT_NT; e4[u] = i < nchg ? list[i] : -1; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s4[u] = e4[u] != -1 ? order[e4[u] & 0xffffff] : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (e4[u] != -1) t4[u] = st.tally[s4[u]];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e4[u] == -1) continue;
+                const int e_ = e4[u];
+                const int y = e_ & 0xffffff, so = (e_ >> 24) & 15, sn = (e_ >> 28) & 15;
+                const int slot = s4[u];
+                Tally nt = t4[u];
+                uint32_t w4 = 0;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {
+                    const uint32_t v = nt.w[b] - ((so != 5 && b != so) ? 1u : 0u) + ((sn != 5 && b != sn) ? 1u : 0u);
+                    nt.w[b] = v;
+                    if (b == 4) w4 = v;
+                }
+                st.tally[slot] = nt;
+                st.colver[slot] = newver;
+                s_i[3] = 1;
+                if (w4 == 0) {
+                    s_i[1] = 1; atomicMin(&s_i[4], y);
+                    const int e = atomicAdd(&s_i[5], 1); if (e < EVCAP) { ev->key[e] = 2 * y; ev->dl[e] = -1; }              // column y loses its last base
+                }
             }
         }
     }

@@ -375,9 +375,11 @@ def test_rccl_path_runs_with_one_rank(oracle):
         assert got == exp
 
 
-def test_bench_two_ranks_rehearsal():
+@pytest.mark.parametrize("split", ["sections", "rows"])
+def test_bench_two_ranks_rehearsal(split):
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), rehearsed on one GPU
-    with gloo: ONE MSA cut into its Window.py sections, sections dealt to the ranks, strong scaling, per-rank times."""
+    with gloo: ONE MSA cut into its Window.py sections, sections dealt to the ranks, strong scaling, per-rank times
+    (default) -- or, --split rows, the whole MSA on both ranks and every batch of the round split between them."""
     import subprocess
     import sys
     from conftest import ROOT
@@ -388,11 +390,13 @@ def test_bench_two_ranks_rehearsal():
     sk.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--workload", "tree_medium", "--backend", "gloo", "--one-device"]
+           "--workload", "tree_medium", "--backend", "gloo", "--one-device", "--split", split]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2
     assert d["value"] > 0 and len(d["per_rank"]) == 2 and all(r["cells"] > 0 for r in d["per_rank"])
-    assert "sections" in d["config"]["workload"]
+    assert ("sections" if split == "sections" else "replica") in d["config"]["workload"]
+    if split == "rows":                                        # every replica committed every row of the two steps
+        assert d["per_rank"][0]["cells"] == d["per_rank"][1]["cells"] == d["roofline"]["cells_reference"]
