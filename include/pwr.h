@@ -119,7 +119,10 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
  *   "seg_rows", "seg_max", "warm_pct", "seg_align", "src_start"
  *               k_fill_v3 fills a DP as up to seg_max (<= 64, default 64) segments of about seg_rows (default 160) rows side
  *               by side, each warmed up while the band moves by warm_pct (default 190) percent of the bandwidth -- from the
- *               column of the base before its first row alone (src_start 1, default) or from the free start of PW:265 (0) -- and CHECKS
+ *               column of the base before its first row alone (src_start 1, default) or from the free start of PW:265 (0); with
+ *               "warm_adapt" 1 (default, needs src_start) warm_pct is the upper bound of a length that follows the failures of the
+ *               check down to "warm_min_pct" (100): "warm_down_pm" (5) per mille of the bandwidth off per fill that passes,
+ *               "warm_up_pm" (50) back on per fill that fails; read-only "warm_now" = the present length in percent -- and CHECKS
  *               every segment's start; a row whose check fails is repeated with twice the warm-up, then in
  *               one piece (pwr_stats.seg_fails).  seg_rows 0 = always in one piece; seg_align (16, 32, 64): the segments' first rows are
  *               multiples of it

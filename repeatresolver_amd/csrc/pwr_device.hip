@@ -66,10 +66,11 @@ struct Hdr {                       // lives in device memory, one per context
     unsigned seq;                  // host copy only: which batch this copy of the header belongs to (written last)
     int need64;                    // > 0: a job needed the 64-bit fill lately; the host launches k_fill64 with the batches while this counts down
     // How long a segment warms up is steered by how often the check fails (k_commit_chain): every segmented fill that passes
-    // takes warm_step columns off, every one that fails puts 20 back on -- the length settles where about one fill in twenty
-    // is repeated, which is where a longer warm-up for all costs as much as the repeats it saves (measured).
+    // takes warm_step columns off, every one that fails puts warm_up (ten times as many) back on -- the length settles where
+    // about one fill in ten is repeated, which is where a longer warm-up for all costs as much as the repeats it saves
+    // (measured).
     // Results never depend on it.  warm_step 0: fixed length (JobBufs::warm_cols).
-    int warm_cur, warm_lo, warm_hi, warm_step;
+    int warm_cur, warm_lo, warm_hi, warm_step, warm_up;   // (warm_up: columns a failure puts back on)
     unsigned long long dbg[32];    // phase timers of commit and trace (10 ns ticks), only written by builds with -DPWR_DIAG
 };
 #ifdef PWR_DIAG
@@ -3345,7 +3346,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs j
                 // realigned again, its fill in one piece
                 if (threadIdx.x == 0) {
                     h->seg_fails += 1; h->noseg_level = h->noseg_row == m->k ? h->noseg_level + 1 : 1; h->noseg_row = m->k;
-                    if (h->noseg_level == 1) h->warm_cur = min(h->warm_hi, h->warm_cur + 20 * h->warm_step);
+                    if (h->noseg_level == 1 && h->warm_step > 0) h->warm_cur = min(h->warm_hi, h->warm_cur + h->warm_up);
                 }
                 stopped = true;
                 continue;
@@ -3590,6 +3591,7 @@ struct pwr_ctx {
     int warm_pct = 190;                   // ... each warmed up while the band moves by this many percent of the bandwidth -- at most: with
     int warm_adapt = 1;                   // "warm_adapt" (and src_start) the length is steered between warm_min_pct and warm_pct by the
     int warm_min_pct = 100;               // failures of the check (Hdr::warm_cur)
+    int warm_down_pm = 5, warm_up_pm = 50;  // ... per mille of the bandwidth a fill that passes takes off / one that fails puts back on
     // stats
     pwr_stats stats{};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -3945,7 +3947,8 @@ static int upload(pwr_ctx *c)
         const long long lo = std::min<long long>(hi, (long long)c->B * c->warm_min_pct / 100 + 2);
         hdr.warm_hi = (int)hi; hdr.warm_lo = (int)lo;
         hdr.warm_cur = (int)std::max(lo, std::min(hi, (long long)c->B * 140 / 100));
-        hdr.warm_step = (c->warm_adapt && c->src_start) ? std::max(1, c->B / 200) : 0;
+        hdr.warm_step = (c->warm_adapt && c->src_start) ? std::max(1, (int)((long long)c->B * c->warm_down_pm / 1000)) : 0;
+        hdr.warm_up = std::max(1, (int)((long long)c->B * c->warm_up_pm / 1000));
     }
     long long *d_rowoff; int *d_rowlen; uint8_t *d_seq;
     if ((rc = dmalloc(c, &st.hdr, 1))) return rc;
@@ -4505,6 +4508,8 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
     if (!strcmp(key, "src_start")) { if (c->on_device || value < 0 || value > 1) return PWR_ERR_ARG; c->src_start = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_adapt")) { if (c->on_device || value < 0 || value > 1) return PWR_ERR_ARG; c->warm_adapt = (int)value; return PWR_OK; }
+    if (!strcmp(key, "warm_down_pm")) { if (c->on_device || value < 1 || value > 1000) return PWR_ERR_ARG; c->warm_down_pm = (int)value; return PWR_OK; }
+    if (!strcmp(key, "warm_up_pm")) { if (c->on_device || value < 1 || value > 10000) return PWR_ERR_ARG; c->warm_up_pm = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_min_pct")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->warm_min_pct = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_pct")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->warm_pct = (int)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9 && value != 17)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
@@ -4533,6 +4538,8 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
         else { Hdr h; int rc = read_hdr(c, &h); if (rc) return rc; *value = h.warm_step > 0 ? (long)(((long long)h.warm_cur * 100 + c->B / 2) / c->B) : c->warm_pct; }
     }
     else if (!strcmp(key, "warm_min_pct")) *value = c->warm_min_pct;
+    else if (!strcmp(key, "warm_down_pm")) *value = c->warm_down_pm;
+    else if (!strcmp(key, "warm_up_pm")) *value = c->warm_up_pm;
     else return PWR_ERR_ARG;
     return PWR_OK;
 }

@@ -26,7 +26,8 @@ class SplitRound:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         if device is None:
             device = torch.cuda.current_device()
-        self.dev = torch.device("cuda", device)
+        # ("cpu": host buffers -- only for tests of the loop and of the records' layout with a stand-in for the context)
+        self.dev = torch.device("cpu") if device == "cpu" else torch.device("cuda", device)
         self.nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
         self.send = self.recv = None
         self.batches = 0
@@ -39,8 +40,9 @@ class SplitRound:
             self.send = torch.zeros(n, dtype=torch.uint8, device=self.dev)
             self.recv = torch.zeros(n * self.world, dtype=torch.uint8, device=self.dev)
             if not self.nccl and self.world > 1:
-                self.h_send = torch.zeros(n, dtype=torch.uint8).pin_memory()
-                self.h_recv = torch.zeros(n * self.world, dtype=torch.uint8).pin_memory()
+                pin = self.dev.type == "cuda"
+                self.h_send = torch.zeros(n, dtype=torch.uint8, pin_memory=pin)
+                self.h_recv = torch.zeros(n * self.world, dtype=torch.uint8, pin_memory=pin)
 
     def _all_gather(self):
         if self.nccl:
@@ -53,7 +55,8 @@ class SplitRound:
             parts = list(self.h_recv.chunk(self.world))
             dist.all_gather(parts, self.h_send, group=self.group)
             self.recv.copy_(self.h_recv)
-        torch.cuda.synchronize(self.dev)           # the commit runs on the context's own stream
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)       # the commit runs on the context's own stream
         self.bytes_gathered += self.recv.numel()
 
     def realign_rows(self, k0, n):

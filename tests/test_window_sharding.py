@@ -109,3 +109,78 @@ def test_sharded_sections_gloo_world2():
     for p, sec in enumerate(secs):
         exp, _ = _oracle_worker(sec, 200, 0, 1)
         assert got[0][p] == exp
+
+
+class _FakeReplica:
+    """Stand-in for a PWReAligner in the per-batch loop of intra_round.SplitRound (no GPU here): records what the loop
+    hands to pwr_split_stage / pwr_split_commit and checks the layout the import kernel relies on -- after the all-gather,
+    rank r's slots_per_rank records lie at offset r * slots_per_rank * slot_bytes."""
+    SLOT, PER_RANK = 48, 2
+
+    def __init__(self, rank, world, T):
+        self.rank, self.world, self.T = rank, world, T
+        self.batch = 0
+        self.left = 0
+        self.errors = []
+
+    def split_begin(self, k0, n, rank, world):
+        assert (rank, world) == (self.rank, self.world)
+        self.left = n
+
+    def split_slot_bytes(self):
+        return self.SLOT, self.PER_RANK
+
+    def _record(self, rank, slot):
+        return bytes(((rank * 31 + slot * 7 + self.batch * 3 + i) & 0xff) for i in range(self.SLOT))
+
+    def split_stage(self, ptr):
+        import ctypes
+        data = b"".join(self._record(self.rank, s) for s in range(self.PER_RANK))
+        ctypes.memmove(ptr, data, len(data))
+
+    def split_commit(self, ptr):
+        import ctypes
+        n = self.SLOT * self.PER_RANK
+        got = ctypes.string_at(ptr, n * self.world)
+        for r in range(self.world):
+            exp = b"".join(self._record(r, s) for s in range(self.PER_RANK))
+            if got[r * n:(r + 1) * n] != exp:
+                self.errors.append((self.batch, r))
+        self.batch += 1
+        self.left = max(0, self.left - 3)                 # (a batch commits a few rows)
+        return self.left
+
+
+def _split_loop_rank_main(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from repeatresolver_amd.intra_round import SplitRound
+    g = _FakeReplica(rank, world, 40)
+    sr = SplitRound(g, device="cpu")
+    sr.realign_round()
+    q.put((rank, g.batch, g.errors, sr.batches, sr.bytes_gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_round_loop_and_record_layout_gloo_world2():
+    """The host side of a round split over ranks (intra_round.py) with two ranks under gloo: stage / all-gather / commit
+    until no row is left, every rank's records where pwr_split_commit expects them."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_split_loop_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, batches, errors, sr_batches, nbytes in got:
+        assert errors == [] and batches == sr_batches == 14        # ceil(40 / 3)
+        assert nbytes == 14 * 2 * _FakeReplica.SLOT * _FakeReplica.PER_RANK
