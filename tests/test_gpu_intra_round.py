@@ -139,3 +139,63 @@ def test_split_round_rccl_branch_with_one_rank(oracle):
     res, st, batches, nbytes = got[0]
     assert res[0][0] == exp[0][0] and res[0][1] == exp[0][1]
     assert st["cells_reference"] == exp[0][2] and nbytes > 0
+
+
+def _fullscale_rank_main(rank, world, port, n, q):
+    import hashlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.intra_round import SplitRound
+    from repeatresolver_amd.realigner import PWReAligner
+    rows = [bytes(r) for r in dg.make_msa("tree_default")]
+
+    def digest(g):
+        h = hashlib.sha256()
+        for r in g.export_rows():
+            h.update(r)
+        return h.hexdigest(), g.total_score(), g.dims()
+
+    res = {}
+    if rank == 0:                                              # the same rows on one context, no split
+        g = PWReAligner(rows, bandwidth=1000, device=0, window=4)
+        g.trim_ends()
+        g.realign_rows(0, n)
+        res["plain"] = digest(g)
+        res["plain_cells"] = g.stats()["cells_reference"]
+        g.close()
+    g = PWReAligner(rows, bandwidth=1000, device=0, window=4)
+    del rows
+    g.trim_ends()
+    SplitRound(g, device=0).realign_rows(0, n)
+    res["split"] = digest(g)
+    st = g.stats()
+    res["split_cells"] = st["cells_reference"]
+    res["computed"] = st["cells_computed"]
+    res["stalls"] = st["stalls"]
+    g.close()
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_round_at_benchmark_scale():
+    """The benchmark MSA (13 510 rows x 136 477 columns), the first rows of round 1: two replicas that split every batch
+    end with the MSA one context reaches alone (which test_gpu_fullscale.py follows row for row with the oracle)."""
+    import multiprocessing as mp
+    n = 96
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fullscale_rank_main, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0]["split"] == got[1]["split"] == got[0]["plain"]
+    assert got[0]["split_cells"] == got[1]["split_cells"] == got[0]["plain_cells"]
+    assert got[0]["computed"] > 0 and got[1]["computed"] > 0
