@@ -14,7 +14,7 @@ SEG_CASES = [("toy_b_b1000", 1000, 1), ("toy_a_b1000", 1000, 2), ("toy_a_b50", 5
              ("deep_b200", 200, 1), ("holes_b300", 300, 2)]
 
 
-@pytest.mark.parametrize("seg_rows,warm_pct,src_start", [(128, 200, 1), (64, 300, 0), (256, 150, 1), (128, 110, 1), (128, 200, 0)])
+@pytest.mark.parametrize("seg_rows,warm_pct,src_start", [(128, 200, 1), (64, 300, 0), (256, 150, 1), (128, 110, 1)])
 @pytest.mark.parametrize("name,bw,rounds", SEG_CASES, ids=[c[0] for c in SEG_CASES])
 def test_segmented_fill_row_by_row(name, bw, rounds, seg_rows, warm_pct, src_start, oracle):
     """Every realignment of the fixtures with their fills cut into small segments: same Way, entry column, placement, MSA --
