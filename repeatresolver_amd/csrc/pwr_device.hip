@@ -127,7 +127,8 @@ struct DState {
 };
 
 // A DP is filled in SEGMENTS that run side by side (k_fill_v3): segment s owns the DP rows [xown, xe) and starts WARM rows
-// earlier, at xb, from the free start of PW:265 (as if row xb were the row's first base).  The fill is a min-plus recurrence
+// earlier, at xb, from a start of its own (one cell: the column of the base before row xb; or the free start of PW:265, as if
+// row xb were the row's first base -- see k_fill_v3).  The fill is a min-plus recurrence
 // whose row vectors forget where they started: after the band has moved past the columns of the start row they are PARALLEL to
 // the true ones (equal up to one additive constant over the whole band), and from there on every comparison the traceback
 // record is made of comes out the same.  Whether the warm-up got there is CHECKED, not assumed (k_seg_check compares the
@@ -1929,7 +1930,7 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
 }
 
 // ---------------------------------------------------------------------------------------------
-// The check behind the segmented fill: segment s (s > 0) started from the free start some hundred rows before its own part;
+// The check behind the segmented fill: segment s (s > 0) started from a start of its own some hundred rows before its own part;
 // its record is the true one iff, in the row before its own part, its scores are PARALLEL to the ones segment s - 1 ends on:
 // the same cells unreachable (>= PWR_INF) and one and the same difference in every other cell of the band -- a min-plus
 // recurrence maps parallel rows to parallel rows, and every bit of the record compares two candidates of one row.  (By
