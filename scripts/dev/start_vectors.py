@@ -47,7 +47,12 @@ class Fill:
             # start vector: 0 inside [c - k, c + k], INF elsewhere
             _, c, k = prev
             r = np.full(len(ys), INF, dtype=np.int64)
-            if k >= 1000:                                 # half-open: free up to c + (k - 1000), unreachable right of it
+            if k >= 3000:                                 # the k - 3000 columns left of c at the price of the gaps between them and c
+                m_ = (ys >= c - (k - 3000)) & (ys <= c) & (ys >= 0)
+                r[m_] = self.G[c] - self.G[ys[m_]]
+            elif k >= 2000:                               # the k - 2000 columns left of c for nothing
+                r[(ys >= c - (k - 2000)) & (ys <= c)] = 0
+            elif k >= 1000:                               # half-open: free up to c + (k - 1000), unreachable right of it
                 r[ys <= c + (k - 1000)] = 0
             else:
                 r[(ys >= c - k) & (ys <= c + k)] = 0
