@@ -96,7 +96,9 @@ def main():
                          "reference feeds PW_ReAligner); truth: the TRUE read-to-template alignments stacked with the same layout rule")
     ap.add_argument("--bandwidth", type=int, default=1000)
     ap.add_argument("--slabs", type=int, default=8, help="steps per realignment round (a step = T/slabs consecutive rows)")
-    ap.add_argument("--sections", type=int, default=6, help="N > 1: Window.py parts the MSA is cut into (configs[3]: 6)")
+    ap.add_argument("--sections", type=int, default=None,
+                    help="Window.py parts the MSA is cut into (N > 1: default 6 = configs[3]; more parts than ranks are dealt by bases, longest first).  "
+                         "With --gpus 1 the parts run as that many contexts side by side on the ONE GPU, each on its own stream: config 4's aggregate rate per GPU")
     ap.add_argument("--window", type=int, default=None)
     ap.add_argument("--split", default="sections", choices=["sections", "rows"],
                     help="N > 1: sections = configs[3], the MSA cut into Window.py sections dealt to the ranks (default); rows = the WHOLE MSA on every "
@@ -159,7 +161,9 @@ def main():
 
     # ---- the units this rank owns
     split_rows_mode = world > 1 and args.split == "rows"
-    if world == 1 or split_rows_mode:
+    if world > 1 and args.sections is None:
+        args.sections = 6
+    if (world == 1 and not args.sections) or split_rows_mode:
         units = [("whole MSA", rows)]
         bounds = None
         owned = [["whole MSA (replica)"] for _ in range(world)]
@@ -192,6 +196,7 @@ def main():
         ctxs.append(g)
     note(f"resident in HBM, score {score0}")
 
+    ctx_seconds = [0.0] * len(ctxs)
     splitters = []
     if split_rows_mode:
         from repeatresolver_amd.intra_round import SplitRound
@@ -204,7 +209,11 @@ def main():
         elif len(ctxs) == 1:
             ctxs[0].realign_rows(k0, k1 - k0)
         elif ctxs:
-            ths = [threading.Thread(target=g.realign_rows, args=(k0, k1 - k0)) for g in ctxs]   # the C calls release the GIL
+            def one(ci, g):
+                t_ = time.perf_counter()
+                g.realign_rows(k0, k1 - k0)
+                ctx_seconds[ci] += time.perf_counter() - t_
+            ths = [threading.Thread(target=one, args=(ci, g)) for ci, g in enumerate(ctxs)]   # the C calls release the GIL
             for th in ths:
                 th.start()
             for th in ths:
@@ -253,15 +262,21 @@ def main():
         fill_s = st["fill_ms"] / 1e3
         launches = max(1, st["fill_launches"])
         timed = max(1, st["fill_launches_timed"])
-        cells_timed = st["cells_computed"] * (timed / launches)     # all launches are timed unless there were > 65536 of them
-        achieved = (cells_timed * BYTES_PER_CELL / fill_s / 1e9) if fill_s > 0 else 0.0
+        # the contract's cells are the REFERENCE's (executions of PW:1503-1510 for the rows realigned) -- warm-up rows and
+        # speculative fills that were thrown away are not throughput.  Every launches/timed-th launch is bracketed by HIP events.
+        achieved = (st["cells_reference"] * (timed / launches) * BYTES_PER_CELL / fill_s / 1e9) if fill_s > 0 else 0.0
+        achieved_all = (st["cells_computed"] * (timed / launches) * BYTES_PER_CELL / fill_s / 1e9) if fill_s > 0 else 0.0
         traffic, traffic_cmd = measured_traffic()
         score1 = sum(g.total_score() for g in ctxs)
         W1 = sum(g.dims()[1] for g in ctxs)
         made = ("the reads cut to their repeat part, aligned into the template by the InitialAligner (GPU, placements identical to the reference's) "
                 "and stacked by Building_MSA: the pipeline's real input" if args.input == "pipeline" else
                 "the MSA stacks the TRUE read-to-template alignments with InitialAligner's layout rule -- it is not an InitialAligner product")
-        if world == 1:
+        if world == 1 and len(ctxs) > 1:
+            wl = (f"{cfg.name} ({args.workload}; {made}) -> {T} rows x {W0} columns cut into {args.sections} Window.py sections {bounds} (BASELINE.json configs[3]), "
+                  f"ALL of them on this one GPU as {len(ctxs)} contexts side by side, each on its own stream; one step = the next {T // args.slabs} rows of "
+                  f"every section; value = the sections' reference cells together / wall time")
+        elif world == 1:
             wl = (f"{cfg.name} ({args.workload}: {cfg.kind}, {cfg.copies} copies, {cfg.coverage:g}x, {cfg.repeat_len} bp; reads simulated with "
                   f"DataSimulator.py's distributions, seed {cfg.seed}; {made}) -> {T} rows x {W0} columns, bandwidth {args.bandwidth}; one step = "
                   f"{args.slabs}th of a realignment round = {T // args.slabs} consecutive rows, steps continue through successive rounds")
@@ -300,25 +315,30 @@ def main():
                        "generate_s": round(gen_s, 1), "input": args.input, "initial_aligner": ia_info, "complete": bool(final)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "frac_useful_cells": (achieved / HBM_PEAK_GBS) * (st["cells_reference"] / st["cells_computed"]) if st["cells_computed"] else None,
+                         "frac_all_computed_cells": achieved_all / HBM_PEAK_GBS,
+                         "frac_end_to_end": (csum * BYTES_PER_CELL / tmax / 1e9 / HBM_PEAK_GBS / max(1, world)) if tmax > 0 else None,
                          "traffic": traffic,
                          "traffic_note": (f"HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of `{traffic_cmd}` (profiles/bench_traffic.json)"
                                           + ("" if traffic_cmd and traffic_cmd.strip() == f"bench.py --steps {args.steps} --warmup {args.warmup}" and not args.opt and args.window is None
                                              else "; NOT this run's command: a committed measurement of another invocation")
                                           if traffic is not None else "no PMC pass of this command is committed"),
-                         "algorithmic_bytes_per_launch": BYTES_PER_CELL * st["cells_computed"] / launches,
+                         "algorithmic_bytes_per_launch": BYTES_PER_CELL * st["cells_reference"] / launches,
                          "kernel": FILL_KERNELS.get(ctxs[0].get_option("fill") if ctxs else 4, "k_fill"),
                          "launches": st["fill_launches"], "launches_timed": st["fill_launches_timed"],
                          "avg_launch_ms": st["fill_ms"] / timed,
-                         "cells_per_launch": st["cells_computed"] / launches,
+                         "cells_per_launch": st["cells_reference"] / launches, "cells_computed_per_launch": st["cells_computed"] / launches,
                          "cells_reference": st["cells_reference"], "cells_computed": st["cells_computed"],
-                         "note": "achieved = DP cells computed by the fill kernel (the warm-up rows of its segments and speculative fills that were "
-                                 "thrown away included: config.useful_frac of them are cells the reference fills) x 4 B / sum of HIP-event durations of "
-                                 "its launches (with its segment check) on the context's stream (rank 0's contexts) -- every launches/launches_timed-th launch is bracketed, "
-                                 "an event record costs ~6 us of stream time; frac_useful_cells counts only the reference's cells"},
+                         "note": "achieved = the REFERENCE's DP cells (PW:1503-1510 executions for the rows committed in the timed steps, SURVEY 8d) x 4 B / sum of "
+                                 "HIP-event durations of the fill kernel's launches on the context's stream (rank 0's contexts; every launches/launches_timed-th "
+                                 "launch is bracketed, an event record costs ~6 us of stream time).  frac_all_computed_cells counts every cell the kernel "
+                                 "touched (warm-up rows of its segments, speculative fills thrown away: 1/config.useful_frac as many); frac_end_to_end = "
+                                 "value x 4 B / peak, all kernels and gaps included"},
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
+        if world == 1 and len(ctxs) > 1:
+            out["per_section"] = [{"section": units[ci][0], "seconds_in_calls": round(ctx_seconds[ci], 3), "cells": g.stats()["cells_reference"],
+                                   "stalls": g.stats()["stalls"], "batches": g.stats()["batches"]} for ci, g in enumerate(ctxs)]
         if world == 1 and not args.no_cpu_baseline and final:
             note("timing the CPU baseline on a bounded sample")
             out["cpu_baseline"] = cpu_baseline(rows, args.bandwidth)
@@ -331,6 +351,7 @@ def main():
         note(f"warm-up step {i + 1}/{args.warmup} done")
     for g in ctxs:
         g.reset_stats()
+    ctx_seconds[:] = [0.0] * len(ctxs)
     fence()
     t0 = time.perf_counter()
     done = 0

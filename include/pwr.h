@@ -107,6 +107,16 @@ int pwr_total_score(pwr_ctx *ctx, uint64_t *total);
 int pwr_dims(pwr_ctx *ctx, int *rows, int *width);
 /* MMA_Auslesen (PW:1556-1598) into memory: rows*width characters, row-major, no newlines. */
 int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
+/* MMA_Auslesen (PW:1556-1598) without waiting for it.  pwr_snapshot_begin takes the image of the FILE the reference would
+ * write now -- `rows` lines of `width` characters "ACGT- ", each followed by '\n' -- on the device, in stream order (calls
+ * that follow may change the state at once), and starts copying it to page-locked host memory on a stream of its own;
+ * pwr_snapshot_wait (any thread) blocks until the image is there: *image stays valid until pwr_snapshot_free.  One snapshot
+ * per context at a time.  pwr_run_file hands the image to a writer thread, so the rewrite of the output after every
+ * improving round (PW:1741) does not hold up the next round. */
+typedef struct pwr_snapshot pwr_snapshot;
+int pwr_snapshot_begin(pwr_ctx *ctx, pwr_snapshot **snap);
+int pwr_snapshot_wait(pwr_snapshot *snap, const unsigned char **image, size_t *bytes, int *rows, int *width);
+void pwr_snapshot_free(pwr_snapshot *snap);
 
 /* Knobs and counters (ours).  Results never depend on any of them.  keys:
  *   "window"    rows gathered / filled per batch, the first certain to commit, the others speculative (1..128, default 3)
@@ -117,7 +127,7 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
  *               k_fill_v3 only; bandwidths above 1000 always use 9
  *   "onewg"     1 = the waves of a k_fill_v3 segment form ONE work-group and hand over through LDS (default 0: measured slower)
  *   "seg_rows", "seg_max", "warm_pct", "seg_align", "src_start"
- *               k_fill_v3 fills a DP as up to seg_max (<= 64, default 64) segments of about seg_rows (default 160) rows side
+ *               k_fill_v3 fills a DP as up to seg_max (<= 256) segments of about seg_rows (default 160) rows side
  *               by side, each warmed up while the band moves by warm_pct (default 190) percent of the bandwidth -- from the
  *               column of the base before its first row alone (src_start 1, default) or from the free start of PW:265 (0); with
  *               "warm_adapt" 1 (default, needs src_start) warm_pct is the upper bound of a length that follows the failures of the
@@ -126,6 +136,11 @@ int pwr_export_rows(pwr_ctx *ctx, unsigned char *buf, size_t cap);
  *               every segment's start; a row whose check fails is repeated with twice the warm-up, then in
  *               one piece (pwr_stats.seg_fails).  seg_rows 0 = always in one piece; seg_align (16, 32, 64): the segments' first rows are
  *               multiples of it
+ *   "seg_budget", "seg_minrows"
+ *               segments the jobs of one batch may have TOGETHER (default 200: about one pipeline wave per SIMD of the chip), dealt
+ *               to them by their rows' lengths -- a long row beside two short ones is cut finer than one of three long rows --,
+ *               none with fewer own rows than seg_minrows (default 64), none with more segments than seg_max (default 256);
+ *               seg_budget 0: about seg_rows rows per segment whatever the batch (the plan of round 3)
  *   "ptrace"    traceback kernel: 2 = k_trace_blk (default: one wave per 64 rows, no hand-over chain), 1 = k_trace_par (64 chunks
  *               handing over top-down), 0 = k_trace_wp (one wave per job)
  *   "slack"     spare column capacity kept when the device arrays are (re)allocated

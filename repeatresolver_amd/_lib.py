@@ -21,7 +21,8 @@ class PwrStats(ctypes.Structure):
 EXPORTS = ["pwr_create", "pwr_destroy", "pwr_trim_ends", "pwr_realign_row", "pwr_realign_round", "pwr_realign_rows",
            "pwr_total_score", "pwr_dims", "pwr_export_rows", "pwr_set_option", "pwr_get_option", "pwr_get_stats",
            "pwr_reset_stats", "pwr_strerror", "pwr_device_count", "pwr_read_msa_file",
-           "pwr_write_msa_file", "pwr_run_file", "pwr_split_begin", "pwr_split_slot_bytes", "pwr_split_stage", "pwr_split_commit"]
+           "pwr_write_msa_file", "pwr_run_file", "pwr_split_begin", "pwr_split_slot_bytes", "pwr_split_stage", "pwr_split_commit",
+           "pwr_snapshot_begin", "pwr_snapshot_wait", "pwr_snapshot_free"]
 
 # every symbol include/pia.h declares (the InitialAligner)
 PIA_EXPORTS = ["pia_create", "pia_destroy", "pia_align", "pia_get_stats", "pia_set_option", "pia_get_timing", "pia_read_template", "pia_read_fasta",

@@ -39,7 +39,7 @@ struct Hdr {                       // lives in device memory, one per context
     int status;                    // sticky error (PWR_ERR_*), 0 = fine
     int stop;                      // batch mode: set when a speculative job failed validation
     int ncommitted;                // batch mode: jobs committed in the current batch
-    int version;                   // bumped by every commit; columns carry the version that last changed them
+    int version;                   // bumped by every commit that changes the state: names the state a job's inputs were gathered from
     unsigned long long cells_computed;
     unsigned long long cells_reference;
     unsigned long long rows_changed;   // commits that changed at least one column
@@ -71,15 +71,8 @@ struct Hdr {                       // lives in device memory, one per context
     // (measured).
     // Results never depend on it.  warm_step 0: fixed length (JobBufs::warm_cols).
     int warm_cur, warm_lo, warm_hi, warm_step, warm_up;   // (warm_up: columns a failure puts back on)
-    unsigned long long dbg[32];    // phase timers of commit and trace (10 ns ticks), only written by builds with -DPWR_DIAG
+    unsigned long long dbg[32];    // phase timers of the traceback (10 ns ticks), only written by builds with -DPWR_DIAG
 };
-#ifdef PWR_DIAG
-#define PH_T0() unsigned long long ph_t_ = __builtin_amdgcn_s_memrealtime();
-#define PH_ADD(H, I) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); if (threadIdx.x == 0) (H)->dbg[I] += n_ - ph_t_; ph_t_ = n_; }
-#else
-#define PH_T0()
-#define PH_ADD(H, I)
-#endif
 
 struct Tally {                     // 32 B per column slot
     uint32_t w[6];                 // PW:46 w_con
@@ -121,7 +114,6 @@ struct DState {
     const long long *brkoff;
     const int *brkx;
     int *nbrk;                     // [T] cleared by the row's first commit
-    unsigned *colver;              // [slotcap] version of the last commit that changed the column's tallies
     int *inscnt;                   // scratch [colcap], kept all-zero between commits
     int *newidx;                   // scratch [colcap]
 };
@@ -134,7 +126,7 @@ struct DState {
 // record is made of comes out the same.  Whether the warm-up got there is CHECKED, not assumed (k_seg_check compares the
 // scores of row xown - 1 as the segment has them with those its predecessor ends on); a job that fails is filled again in
 // one piece.  (Rank convergence of tropical DP; measured for this band: scripts/dev/rank_convergence.py.)
-#define SEG_MAX 64
+#define SEG_MAX 256
 struct SegDesc {
     int job, s;                    // job slot, index of the segment within the job
     int xb, xown, xe;              // warm-up from xb, own rows [xown, xe)
@@ -143,6 +135,13 @@ struct SegDesc {
     unsigned long long cells;      // DP cells of the rows [xb, xe)
 };
 struct GatherPart;
+struct CommitJob {                  // what k_commit_scan found out about a job (reset by the job's gather)
+    int nchg, nev, ndel, first;     // columns whose symbol changes, structural events, columns emptied, first ordinal with an event
+    int u0, u1;                     // the columns the row covers before or after: every change lies in [u0, u1], every event in [u0 - 1, u1]
+    int scanned, pad;
+};
+struct BatchPlan;
+struct CommitEv;
 struct JobBufs {
     GatherPart *gpart;             // [njobs][GATHER_G] partial results of the gather's shares
     unsigned gather_tag;           // launch counter of the gather (tags the partial results)
@@ -163,6 +162,8 @@ struct JobBufs {
     int seg_align;                 // own parts start at multiples of this (16, 32 or 64)
     int src_start;                 // 1: a warm-up starts from the column of the base before it alone (k_fill_v3), 0: from the free start
     int smax, seg_rows, warm_cols; // at most smax segments per job, of about seg_rows own rows, warmed up over warm_cols columns of band movement
+    int seg_budget, seg_minrows;   // segments all jobs of a batch may have together (dealt by length), none with fewer own rows than seg_minrows
+    const int *rowids;             // the slab's rows (the plan of a job looks at the lengths of the batch's other jobs)
     int gstride;                   // rows per wave of a job's mailbox area
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
     unsigned long long *gtr;       // [njobs][trk]    k_trace_par / k_trace_blk: hand-over words of the chunks
@@ -184,6 +185,16 @@ struct JobBufs {
     // job of a batch, but fills and traces only the jobs j with j % split_world == split_rank; the others' placements arrive
     // through the all-gather, and every rank commits all of them in row order.  split_world <= 1: everything is this rank's.
     int split_rank, split_world;
+    // commit (k_commit_scan / _apply / _finish)
+    CommitJob *cjob;               // [njobs] what the scan found out about a job
+    int *chg;                      // [njobs][colcap] columns whose symbol for the row changes: y | old symbol << 24 | new symbol << 28
+    int *evkey, *evdl;             // [njobs][EVCAP] structural events: 2y + 1 a column opens after y (+1), 2y column y is emptied (-1)
+    int *insidx;                   // [njobs][Lmax] for a base that opens a column: its number among the row's new columns
+    int *pair_cf, *pair_left;      // [njobs][njobs] (i, j > i): a change of job i lies in job j's interval; net columns job i opens left of it
+    BatchPlan *plan;               // which jobs of the batch commit (written by k_commit_apply's first work-group)
+    CommitEv *sev;                 // the batch's structural events, sorted (the same)
+    int *freed;                    // [EVCAP] slots of the columns the batch empties
+    unsigned *ticket;              // arrivals at the end of k_commit_finish
 };
 #define NOT_MINE(JB, JOB) ((JB).split_world > 1 && (JOB) % (JB).split_world != (JB).split_rank)
 
@@ -314,6 +325,12 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, c
     const Hdr *hd = st.hdr;
     int boff;
     const int kk = gather_row_of(hd, job, &boff);
+    if (g == 0) {
+        // what the commit of this batch will note about the job (k_commit_scan) starts from nothing
+        const int nj = (int)gridDim.x;
+        if (tid == 0) { CommitJob z; z.nchg = z.nev = z.ndel = 0; z.first = 0x7fffffff; z.u0 = z.u1 = 0; z.scanned = 0; z.pad = 0; jb.cjob[job] = z; }
+        for (int j = tid; j < nj; j += GATHER_NT) { jb.pair_cf[(size_t)job * nj + j] = 0; jb.pair_left[(size_t)job * nj + j] = 0; }
+    }
     if (kk < 0) { if (tid == 0 && g == 0) m->active = 0; return; }
     const int k = jobrows[kk];
     const int L = st.rowlen[k];
@@ -418,8 +435,28 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
     if (tid == 0) {
         int S = 1;
         const int level = st.hdr->noseg_row == m->k ? st.hdr->noseg_level : 0;     // how often this row's check has failed
-        if (jb.seg_rows > 0 && level < 2) S = (L + jb.seg_rows / 2) / jb.seg_rows;
-        S = max(1, min(S, min(jb.smax, L / 128)));
+        if (jb.seg_rows > 0 && level < 2) {
+            // A launch ends with its longest chain of rows: own rows + warm-up of the job with the fewest segments per base.  The
+            // chip holds about one worker wave per SIMD (seg_budget segments of NW waves) before the waves start to share issue
+            // slots, so the batch's jobs are dealt the budget by their lengths: a long row next to two short ones is cut finer
+            // than one of three long rows, and three short rows are cut finer than seg_rows asks for because there is room (every
+            // job's plan sees the lengths of the others: the rows of a batch follow from the header).  Never finer than
+            // seg_minrows own rows.  seg_budget 0: about seg_rows rows each, as many as that gives.
+            const int natural = min((L + jb.seg_rows / 2) / jb.seg_rows, L / 128);
+            S = natural;
+            if (jb.seg_budget > 0) {
+                const Hdr *hd = st.hdr;
+                long long Lsum = 0;
+                for (int j = 0; j < hd->nb; ++j) {
+                    int bo;
+                    const int kj = gather_row_of(hd, j, &bo);
+                    if (kj >= 0) Lsum += st.rowlen[jb.rowids[kj]];
+                }
+                Lsum = max(Lsum, (long long)L);
+                S = min((int)((long long)jb.seg_budget * L / Lsum), L / max(16, jb.seg_minrows));
+            }
+        }
+        S = max(1, min(S, jb.smax));
         s_S = S;
         // (a row whose check failed: the longest warm-up the steering allows, twice that if it was already there)
         const Hdr *hd = st.hdr;
@@ -436,8 +473,10 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
         // xb of segment s: the largest multiple of 16 below x_s whose row sits at least `warm` columns left of row x_s (Way[]
         // is increasing).  Sixteen threads per segment, a 16-ary search: three dependent loads instead of twelve (this share
         // would otherwise be the one its kernel waits for).
-        static_assert(SEG_MAX * 16 <= GATHER_NT, "sixteen threads per segment");
-        const int sgi = tid >> 4, li = tid & 15;
+        static_assert(SEG_MAX % (GATHER_NT / 16) == 0, "sixteen threads per segment, GATHER_NT / 16 segments per pass");
+      for (int pass = 0; pass < SEG_MAX / (GATHER_NT / 16); ++pass) {
+        if (pass * (GATHER_NT / 16) >= S) break;                 // (uniform)
+        const int sgi = pass * (GATHER_NT / 16) + (tid >> 4), li = tid & 15;
         int lo_c = -1, hi_c = 0, lim = 0;                        // candidates 16 * c: c <= lo_c hold, c >= hi_c do not
         if (sgi > 0 && sgi < S) { const int xs = s_x[sgi]; lim = way[xs] - warm; hi_c = xs / 16; }
         for (int round = 0; round < 8; ++round) {                // (16^3 = 4096 candidates cover 35 000 rows; the bound is slack)
@@ -457,6 +496,7 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
             if (__syncthreads_or(hi_c - lo_c - 1 > 0) == 0) break;
         }
         if (li == 0 && sgi < S) s_xb[sgi] = (sgi == 0 || lo_c < 0) ? 0 : 16 * lo_c;
+      }
     }
     __syncthreads();
     // cells of the rows [xb, xe): B each, less what the MSA's right edge cuts off the band (PW:1497) -- only the rows from
@@ -2861,13 +2901,28 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
 }
 
 // ---------------------------------------------------------------------------------------------
-// commit: apply one job's new placement to the resident state (one work-group):
-//   Column_Updater (PW:1222-1243) for every existing column the row touches, Column_Adder
-//   (PW:1245-1332) for every new column, then W_Con (PW:706-763): drop columns without a base and
-//   renumber.  AlGapCount of PW:1305-1314 ("rows non-blank on both sides of the new column") is
-//   coverage(y) - rows ending in y, both taken with the realigned row removed.
+// commit: Column_Updater (PW:1222-1243) for every existing column a realigned row touches, Column_Adder (PW:1245-1332) for
+// every column it opens, then W_Con (PW:706-763): drop the columns without a base and renumber -- for ALL the jobs of a batch
+// that may commit, spread over the chip in three launches (round 3: one work-group that walked the jobs one after the other,
+// 68 us per batch; a kernel boundary costs less than a grid barrier inside a launch, so the phases are launches):
+//   k_commit_scan    (job, share): WHAT a job's new placement changes, without touching the state: the columns whose symbol for
+//                    the row changes, the columns it opens (with their AlGapCount, PW:1305-1314 = coverage - rows ending there,
+//                    both without the row) and the columns it empties -- and which of that lies in the band interval of a LATER
+//                    job of the batch (the jobs of a batch are all gathered from the same state, in the same numbering);
+//   k_commit_apply   decides which jobs commit -- in row order; a job is exact iff no job committed before it changes anything
+//                    inside its interval [lo, hi] (every column its DP read) and the clamps at the MSA's edges see the same
+//                    distances (PW:1496-1497, 1505); a job may go AHEAD of a stale one when their intervals are disjoint --,
+//                    applies the changes of all of them (their column sets are disjoint by that very rule), and copies the
+//                    stretches of the order that move out to a scratch array;
+//   k_commit_finish  moves them to their new ordinals, places the new columns, frees the emptied ones, and the last work-group
+//                    to arrive writes the header: width, row pointer, the next batch's size, the copy for the host.
 // ---------------------------------------------------------------------------------------------
 #define COMMIT_NT 1024
+#define EVCAP 1024                  // structural events (columns opened / emptied) of one BATCH handled without a pass over the width
+#define MAXJ 128                    // jobs of a batch ("window" <= 128)
+#define CS_G 16                     // shares of a job in k_commit_scan
+#define CA_G 32                     // work-groups of k_commit_apply / k_commit_finish
+
 // symbol of the realigned row in existing column y: base+? from a mark array inside [y0,y1], blank outside
 __device__ __forceinline__ int row_symbol(const uint8_t *mk, int y, int lo, int y0, int y1)
 {
@@ -2876,302 +2931,455 @@ __device__ __forceinline__ int row_symbol(const uint8_t *mk, int y, int lo, int 
     return v == 7 ? 5 : (v ? v - 1 : 4);                  // 7: a blank run between two segments of the row
 }
 
-#define EVCAP 1024                  // structural events (columns opened / emptied) of one commit handled without a pass over the width
-struct CommitEv { int key[EVCAP], dl[EVCAP], skey[EVCAP], scum[EVCAP], seg_lo[EVCAP + 1], seg_sh[EVCAP + 1], seg_pre[EVCAP + 2], cpre[COMMIT_NT]; };
+enum { V_NONE = 0, V_COMMIT, V_STALE, V_STOP_NOTOK, V_STOP_GROW, V_STOP_WIDE, V_STOP_ABORT, V_STOP_SEGFAIL, V_EMPTY, V_AFTER_STOP };
+struct BatchPlan {
+    int idle;                       // sticky error or capacity shortage: the batch does nothing
+    int ncommit, nnew, ndel, nev;   // jobs that commit; columns they open / empty; their structural events
+    int restructure, big;           // the order changes; ... by a pass over the width (more than evcap events)
+    int live_all, live_done, ahead_n;
+    int first;                      // first ordinal that changes
+    unsigned long long done_mask;
+    int reasons[4];
+    int cjobs[MAXJ], slotbase[MAXJ];          // the committing jobs in row order; index of a job's first new column among the batch's
+    signed char verdict[MAXJ];
+};
+struct CommitEv { int key[EVCAP], dl[EVCAP], skey[EVCAP], scum[EVCAP], seg_lo[EVCAP + 1], seg_sh[EVCAP + 1], seg_pre[EVCAP + 2]; int ns, cum, nev, pad; };
 
-__device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_i, CommitEv *ev)
+__global__ __launch_bounds__(COMMIT_NT) void k_commit_scan(DState st, JobBufs jb, int njobs)
 {
-    const int tid = threadIdx.x;
-    Hdr *h = st.hdr;
-    JobMeta *m = &jb.meta[job];
-    const int L = m->L;
-    const int W = h->W;
-    const int cur = h->cur;
-    const int *order = cur ? st.order1 : st.order0;
-    int *norder = cur ? st.order0 : st.order1;
-    const int k = m->k;
+    __shared__ unsigned sh[COMMIT_NT / 64];
+    __shared__ int s_cpre[COMMIT_NT];
+    __shared__ int s_ov[MAXJ], s_ovlo[MAXJ], s_ovhi[MAXJ], s_nov;
+    const int job = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
+    const JobMeta *m = &jb.meta[job];
+    if (st.hdr->status != 0 || st.hdr->need_grow) return;
+    if (!m->active || m->L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows)) return;   // cannot commit in this batch
+    const int k = m->k, L = m->L;
+    if (!m->changed && st.nbrk[k] == 0) return;           // the traceback left every base where it was (k_trace_blk): nothing changes
+    const int nch = (L + 63) >> 6;
+    const bool chunked = jb.trace_blk != 0 && nch <= COMMIT_NT;     // k_trace_blk counted the 'up' moves of every 64 rows
+    const int G = (chunked && L >= 64 * CS_G) ? CS_G : 1;
+    if (g >= G) return;
+    CommitJob *cj = &jb.cjob[job];
     const long long off = st.rowoff[k];
     const int lo = m->lo;
+    const int *order = cur_order(st);
     const int *way = jb.way + (size_t)job * jb.Lmax;
     const int *newcol = jb.newcol + (size_t)job * jb.Lmax;
     int *aux = jb.aux + (size_t)job * jb.Lmax;
+    int *insidx = jb.insidx + (size_t)job * jb.Lmax;
     const uint8_t *mark = jb.mark + (size_t)job * jb.colcap;
     uint8_t *mark2 = jb.mark2 + (size_t)job * jb.colcap;
+    int *list = jb.chg + (size_t)job * jb.colcap;
+    int *evkey = jb.evkey + (size_t)job * EVCAP, *evdl = jb.evdl + (size_t)job * EVCAP;
     const int way0 = way[0], wayL = way[L - 1];
     const int nc0 = newcol[0], ncL = newcol[L - 1];
     const int ny0 = (nc0 >> 1) + (nc0 & 1), nyL = ncL >> 1;   // existing columns inside the new row extent
-    const int nnew = m->nnew;
-    const int nfree = h->nfree, nslots = h->nslots;
-    const int take = min(nnew, nfree);
-    const unsigned newver = (unsigned)h->version + 1u;
-    if (!m->changed && st.nbrk[k] == 0) {
-        // The traceback put every base back where it was and opened no column (k_trace_blk): no tally, no slot, no ordinal
-        // changes -- most rows of the later rounds.  (A row read with blank runs between its bases is joined by its first
-        // commit even then: it takes the long way.)
-        if (tid == 0) h->cells_reference += m->cells;
-        __syncthreads();
-        return;
+    const int u0 = min(way0, ny0), u1 = max(wayL, nyL);
+    // A share takes the bases [x0, x1) and the columns from its first base's place up to the next share's: the marks of the new
+    // placement in those columns are written by its own bases only, so nothing is handed over between the shares.
+    const int x0 = G == 1 ? 0 : (int)(((long long)L * g / G) & ~63LL);
+    const int x1 = (G == 1 || g == G - 1) ? L : (int)(((long long)L * (g + 1) / G) & ~63LL);
+    auto colpos = [](int c) { return (c >> 1) + (c & 1); };     // the first existing column at or right of a base's place
+    const int Y0 = g == 0 ? u0 : colpos(newcol[x0]), Y1 = g == G - 1 ? u1 + 1 : colpos(newcol[x1]);
+    if (tid == 0) {
+        // the later jobs of the batch whose interval comes near this job's columns: only they can be touched
+        int n = 0;
+        for (int j = job + 1; j < njobs; ++j) {
+            const JobMeta *mj = &jb.meta[j];
+            if (!mj->active) break;
+            if (mj->L <= 0) continue;
+            if (mj->lo - 2 <= u1 + 2 && mj->hi + 2 >= u0 - 2) { s_ov[n] = j; s_ovlo[n] = mj->lo; s_ovhi[n] = mj->hi; ++n; }
+        }
+        s_nov = n;
+        if (g == 0) { cj->u0 = u0; cj->u1 = u1; cj->scanned = 1; }
     }
-    PH_T0()
-    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[3] = 0; s_i[4] = 0x7fffffff; s_i[5] = 0; s_i[8] = 0; }   // [8] changed columns, [0] freed slots, [1] some column lost its last base, [3] any change, [4] first ordinal that changes, [5] structural events
-    {
-        // (whole 8-byte units: the bytes around the new extent belong to nobody else, symbols outside it are decided by the extent)
-        unsigned long long *m8 = reinterpret_cast<unsigned long long *>(mark2);
-        for (int u = ((ny0 - lo) >> 3) + tid; u <= ((nyL - lo) >> 3); u += COMMIT_NT) m8[u] = 0ull;
-    }
-    __syncthreads();
-    PH_ADD(h, 1)
-    // 1. new columns (PW:1245-1332), the slot of every base (into `pos` at once: nothing below reads this row's), and the
-    //    marks of the new placement.  The tallies of the neighbour column y are read as the trace saw them: the row's old
-    //    symbol taken out, the new one not yet put in.
-    unsigned carry = 0;
-    // Which new column is a base's (idx: the number of columns opened by the bases before it)?  k_trace_blk has counted the
-    // 'up' moves of every 64 rows: a prefix over its chunks and a ballot inside the wave give idx without a block scan per
-    // 1024 bases; the other traceback kernels leave the scan to this loop.
-    const bool by_chunk = jb.trace_blk != 0 && ((L + 63) >> 6) <= COMMIT_NT;
-    if (by_chunk) {
+    for (int y = Y0 + tid; y < Y1; y += COMMIT_NT) mark2[y - lo] = 0;
+    if (chunked) {
         const unsigned long long *hand = jb.gtr + (size_t)job * jb.trk;
-        const int nch = (L + 63) >> 6;
         const unsigned mine = tid < nch ? (unsigned)((hand[tid] >> 41) & 0x7full) : 0u;
         unsigned tot;
         const unsigned incl = block_incl_add<COMMIT_NT>(mine, sh, tot);
-        ev->cpre[tid] = (int)(incl - mine);
-        __syncthreads();
+        s_cpre[tid] = (int)(incl - mine);
     }
-    // (four bases per thread and turn: their placements, then the slots of their columns, are loaded side by side -- the
-    // loop is a chain of dependent loads, and with one base per turn it cost ten round trips to memory per 10 000 bases)
-    for (int base4 = 0; base4 < L; base4 += 4 * COMMIT_NT) {
-      int c4[4], sl4[4], bs4[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int x = base4 + u * COMMIT_NT + tid; c4[u] = (x < L) ? newcol[x] : 0; bs4[u] = (x < L) ? (int)st.seq[off + x] : 0; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int x = base4 + u * COMMIT_NT + tid; sl4[u] = (x < L) ? order[c4[u] >> 1] : 0; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int base = base4 + u * COMMIT_NT;
-        if (base >= L) break;
+    __syncthreads();
+    const int nov = s_nov;
+    // a change in column y (dl != 0: a column opens after y / column y is emptied) against the intervals of the later jobs
+    auto touch = [&](int y, int dl) {
+        for (int t = 0; t < nov; ++t) {
+            if (y >= s_ovlo[t] - 1 && y <= s_ovhi[t] + 1) jb.pair_cf[(size_t)job * njobs + s_ov[t]] = 1;
+            else if (dl != 0 && y < s_ovlo[t] - 1) atomicAdd(&jb.pair_left[(size_t)job * njobs + s_ov[t]], dl);
+        }
+    };
+    auto event = [&](int key, int dl) {
+        const int e = atomicAdd(&cj->nev, 1);
+        if (e < EVCAP) { evkey[e] = key; evdl[e] = dl; }
+        atomicMin(&cj->first, key >> 1);
+    };
+    // 1. the bases: the marks of the new placement; for every column a base opens its AlGapCount and its number among the row's
+    //    new columns.  The tallies of the neighbour column y are read as the trace saw them (the state is still the gather's):
+    //    the row's old symbol taken out, the new one not yet put in.
+    unsigned carry = 0;
+    for (int base = x0; base < x1; base += COMMIT_NT) {
         const int x = base + tid;
-        const int c = c4[u];
-        const unsigned ins = (x < L && (c & 1)) ? 1u : 0u;
+        const int c = x < x1 ? newcol[x] : 0;
+        const unsigned ins = (x < x1 && (c & 1)) ? 1u : 0u;
         int idx;
-        if (by_chunk) {
+        if (chunked) {
             const unsigned long long bal = __ballot(ins != 0u);
-            idx = ev->cpre[min(x, L - 1) >> 6] + __builtin_popcountll(bal & ((1ull << (tid & 63)) - 1ull));
+            idx = s_cpre[min(x, L - 1) >> 6] + __builtin_popcountll(bal & ((1ull << (tid & 63)) - 1ull));
         } else {
             unsigned tot;
             const unsigned incl = block_incl_add<COMMIT_NT>(ins, sh, tot);
             idx = (int)(carry + incl - ins);
             carry += tot;
         }
-        if (x < L) {
+        if (x < x1) {
             const int y = c >> 1;
-            const int sloty = sl4[u];
             if (ins) {
-                const int slot = (idx < take) ? st.freelist[nfree - 1 - idx] : nslots + (idx - take);
-                const int bs = bs4[u];
-                const Tally ty = st.tally[sloty];
+                const Tally ty = st.tally[order[y]];
                 // (the row itself out of both counts; between two of its segments it is blank, and a segment's last column
                 // counts as an end -- rows read with interior blanks, until this commit)
                 const bool own_nb = row_symbol(mark, y, lo, way0, wayL) != 5;
                 const bool own_end = own_nb && (y == wayL || row_symbol(mark, y + 1, lo, way0, wayL) == 5);
                 const uint32_t cov = ty.w[5] - (own_nb ? 1u : 0u);
                 const uint32_t ends = ty.endcnt - (own_end ? 1u : 0u);
-                const uint32_t al = cov - ends;                                    // PW:1305-1314
-                Tally nt;
-#pragma unroll
-                for (int b = 0; b < 6; ++b) nt.w[b] = ((b != bs) ? 1u : 0u) + ((b != 4) ? al : 0u);   // PW:1320-1325
-                nt.endcnt = 0; nt.pad = 0;
-                st.tally[slot] = nt;
-                st.colver[slot] = newver;
-                atomicAdd(&st.inscnt[y], 1);
-                atomicMin(&s_i[4], y);
-                { const int e = atomicAdd(&s_i[5], 1); if (e < EVCAP) { ev->key[e] = 2 * y + 1; ev->dl[e] = 1; } }   // a column opens after y
-                aux[x] = slot;
-                st.pos[off + x] = slot;
-            } else {
-                aux[x] = sloty;
-                st.pos[off + x] = sloty;
-                mark2[y - lo] = (uint8_t)(bs4[u] + 1);
-            }
+                aux[x] = (int)(cov - ends);                                        // PW:1305-1314
+                insidx[x] = idx;
+                event(2 * y + 1, 1);                                               // a column opens after y
+                touch(y, 1);
+            } else mark2[y - lo] = (uint8_t)(st.seq[off + x] + 1);
         }
-      }
     }
     __syncthreads();
-    PH_ADD(h, 2)
-    // 2. Columns_Downdater + Column_Updater fused (PW:1172-1243): only columns whose symbol for this
-    //    row really changes are touched (and stamped with the new version)
-    const int u0 = min(way0, ny0), u1 = max(wayL, nyL);
-    // (a) find them, eight columns at a time: a unit that lies inside both extents and holds the same marks before and after
-    //     has none; (b) one thread per changed column
+    // 2. the columns: where the row's symbol changes (eight at a time: a unit inside both extents that holds the same marks
+    //    before and after has none), and which of them lose their last base
     {
         const unsigned long long *mo8 = reinterpret_cast<const unsigned long long *>(mark), *mn8 = reinterpret_cast<const unsigned long long *>(mark2);
         const int ui0 = max(way0, ny0), ui1 = min(wayL, nyL);                      // columns inside both extents
-        int *list = st.newidx;                                                     // (scratch until the renumbering)
-        for (int u = ((u0 - lo) >> 3) + tid; u <= ((u1 - lo) >> 3); u += COMMIT_NT) {
+        for (int u = ((Y0 - lo) >> 3) + tid; u <= ((Y1 - 1 - lo) >> 3); u += COMMIT_NT) {
             const int yb8 = lo + 8 * u;
             const unsigned long long wo = mo8[u], wn = mn8[u];
             if (yb8 >= ui0 && yb8 + 7 <= ui1 && wo == wn) continue;
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
                 const int y = yb8 + b;
-                if (y < u0 || y > u1) continue;
+                if (y < Y0 || y >= Y1 || y < u0 || y > u1) continue;               // (the unit's other bytes are a neighbour share's)
                 const int vo = (int)((wo >> (8 * b)) & 0xffull), vn = (int)((wn >> (8 * b)) & 0xffull);
                 const int so = (y < way0 || y > wayL) ? 5 : (vo == 7 ? 5 : (vo ? vo - 1 : 4));     // row_symbol()
                 const int sn = (y < ny0 || y > nyL) ? 5 : (vn == 7 ? 5 : (vn ? vn - 1 : 4));
-                if (so != sn) list[atomicAdd(&s_i[8], 1)] = y | (so << 24) | (sn << 28);
-            }
-        }
-        __syncthreads();
-        const int nchg = s_i[8];
-        // (four changed columns per thread and turn, every column is in the list once: entries, slots and tallies are
-        // loaded side by side)
-        for (int i4 = tid; i4 < nchg; i4 += 4 * COMMIT_NT) {
-            int e4[4], s4[4];
-            Tally t4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = i4 + u * COMMIT_NT; e4[u] = i < nchg ? list[i] : -1; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) s4[u] = e4[u] != -1 ? order[e4[u] & 0xffffff] : 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (e4[u] != -1) t4[u] = st.tally[s4[u]];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (e4[u] == -1) continue;
-                const int e_ = e4[u];
-                const int y = e_ & 0xffffff, so = (e_ >> 24) & 15, sn = (e_ >> 28) & 15;
-                const int slot = s4[u];
-                Tally nt = t4[u];
-                uint32_t w4 = 0;
-#pragma unroll
-                for (int b = 0; b < 6; ++b) {
-                    const uint32_t v = nt.w[b] - ((so != 5 && b != so) ? 1u : 0u) + ((sn != 5 && b != sn) ? 1u : 0u);
-                    nt.w[b] = v;
-                    if (b == 4) w4 = v;
-                }
-                st.tally[slot] = nt;
-                st.colver[slot] = newver;
-                s_i[3] = 1;
-                if (w4 == 0) {
-                    s_i[1] = 1; atomicMin(&s_i[4], y);
-                    const int e = atomicAdd(&s_i[5], 1); if (e < EVCAP) { ev->key[e] = 2 * y; ev->dl[e] = -1; }              // column y loses its last base
+                if (so == sn) continue;
+                list[atomicAdd(&cj->nchg, 1)] = y | (so << 24) | (sn << 28);
+                touch(y, 0);
+                if (so < 4 && sn >= 4 && st.tally[order[y]].w[4] == 1u) {          // the row's base was the column's last: W_Con will drop it
+                    event(2 * y, -1);
+                    atomicAdd(&cj->ndel, 1);
+                    touch(y, -1);
                 }
             }
         }
+    }
+}
+
+// Which jobs of the batch commit (one thread; every work-group of k_commit_apply works it out for itself, from data no kernel
+// of the batch changes before k_commit_finish's last work-group).  Jobs in row order.  A stale job -- something a job committed
+// before it changes lies in its interval -- is left for the next batch, and a later job may still commit AHEAD of it when the
+// two commute: their band intervals are disjoint (with a margin for the column a commit may open at its interval's edge, and
+// for the columns the commits before have opened or emptied inside the stale row's interval, which its NEXT gather will see
+// shifted by as many).  The DP depends on absolute positions only through the clamps at the MSA's edges, which disjoint
+// intervals rule out (commutation probe), so realigning j after i gives the state the reference reaches with j before i.
+__device__ void commit_decide(const DState &st, const JobBufs &jb, int njobs, BatchPlan *p)
+{
+    const Hdr *h = st.hdr;
+    p->idle = (h->status != 0 || h->need_grow) ? 1 : 0;
+    p->ncommit = p->nnew = p->ndel = p->nev = p->restructure = p->big = 0;
+    p->live_all = p->live_done = p->ahead_n = 0;
+    p->first = 0x7fffffff;
+    p->done_mask = 0ull;
+    for (int i = 0; i < 4; ++i) p->reasons[i] = 0;
+    for (int j = 0; j < njobs && j < MAXJ; ++j) p->verdict[j] = V_NONE;
+    if (p->idle) return;
+    const int W = h->W, H = st.H, B = st.B;
+    int net = 0, evabs = 0, nskip = 0;
+    int skipped[MAXJ];
+    bool stopped = false;
+    for (int j = 0; j < njobs && j < MAXJ; ++j) {
+        const JobMeta *m = &jb.meta[j];
+        if (!m->active) break;                                                    // the batch ends here
+        if (m->L > 0) {
+            p->live_all += 1;
+            if (stopped) { p->verdict[j] = V_AFTER_STOP; continue; }
+            if (!m->ok) { p->verdict[j] = V_STOP_NOTOK; stopped = true; continue; }            // status already set
+            // room for the columns this commit may open?  (the host regrows the arrays and the batch is repeated)
+            if ((long long)W + p->nnew + m->L + 64 > st.colcap || (long long)h->nslots + p->nnew + m->L + 64 > st.slotcap) { p->verdict[j] = V_STOP_GROW; stopped = true; continue; }
+            if (m->wide && !jb.f64_follows) { p->verdict[j] = V_STOP_WIDE; stopped = true; continue; }   // (its batch came without k_fill64: the next ones bring it)
+            if (m->abort) { p->verdict[j] = V_STOP_ABORT; stopped = true; continue; }
+            if (m->segfail) { p->verdict[j] = V_STOP_SEGFAIL; stopped = true; continue; }
+            bool good = true;
+            int why = -1;
+            int d = 0, r = 0;                                                     // columns the jobs committed before open (net) left / right of this job's interval
+            for (int t = 0; t < p->ncommit && good; ++t) {
+                const int i = p->cjobs[t];
+                const CommitJob *ci = &jb.cjob[i];
+                if (!ci->scanned) continue;                                       // (committed without a change)
+                if (jb.pair_cf[(size_t)i * njobs + j]) { good = false; why = 3; break; }
+                const int neti = jb.meta[i].nnew - ci->ndel;
+                int left;
+                if (ci->u1 < m->lo - 1) left = neti;                              // all its events lie left of the interval's margin
+                else if (m->hi + 1 < ci->u0 - 1) left = 0;                        // ... right of it
+                else left = jb.pair_left[(size_t)i * njobs + j];
+                d += left; r += neti - left;
+            }
+            if (good && (d != 0 || r != 0)) {
+                const int *way = jb.way + (size_t)j * jb.Lmax;
+                const int way0 = way[0], wayL = way[m->L - 1];
+                if (d != 0 && !(way0 - H >= 1 && way0 + d - H >= 1)) { good = false; why = 1; }           // left clamp PW:1496
+                const int aL = max(0, wayL - H);
+                const bool far_old = aL + B <= m->W - 1, far_new = aL + d + B <= W + net - 1;
+                if (good && !(far_old && far_new) && r != 0) { good = false; why = 2; }                   // right clamp PW:1497/1505
+            }
+            for (int t = 0; t < nskip && good; ++t) {
+                const JobMeta *ms = &jb.meta[skipped[t]];
+                if (!(m->hi + 2 + evabs < ms->lo || ms->hi + 2 + evabs < m->lo)) good = false;
+            }
+            if (!good) {
+                if (why >= 0) p->reasons[why] += 1;
+                if (nskip >= MAXJ) { p->verdict[j] = V_AFTER_STOP; stopped = true; continue; }
+                skipped[nskip++] = j;
+                p->verdict[j] = V_STALE;
+                continue;
+            }
+            p->verdict[j] = V_COMMIT;
+            p->cjobs[p->ncommit] = j; p->slotbase[p->ncommit] = p->nnew;
+            p->ncommit += 1;
+            const CommitJob *cj = &jb.cjob[j];
+            if (cj->scanned) {
+                p->nnew += m->nnew; p->ndel += cj->ndel; p->nev += cj->nev;
+                net += m->nnew - cj->ndel; evabs += cj->nev;
+                if (m->nnew > 0 || cj->ndel > 0) { p->restructure = 1; p->first = min(p->first, cj->first); }
+                if (cj->nev > EVCAP) p->big = 1;
+            }
+            p->live_done += 1;
+            if (nskip > 0) p->ahead_n += 1;
+        } else p->verdict[j] = V_EMPTY;                                           // (a row without bases, PW:1488, is done wherever it stands)
+        if (m->off < 64) p->done_mask |= 1ull << m->off; else stopped = true;
+    }
+    if (p->nev > jb.evcap || p->nev > EVCAP) p->big = 1;
+    if (!p->restructure) p->big = 0;
+}
+
+// the events of the committing jobs, sorted by position (key 2y: column y is emptied, 2y+1: a column opens after y); an old
+// ordinal y moves by the sum of the events with key < 2y; only the stretches between events whose shifts do not cancel move
+__device__ void commit_sort_events(const JobBufs &jb, const BatchPlan *p, int W, CommitEv *ev)
+{
+    const int tid = threadIdx.x;
+    int base = 0;
+    for (int t = 0; t < p->ncommit; ++t) {
+        const int j = p->cjobs[t];
+        const CommitJob *cj = &jb.cjob[j];
+        if (!cj->scanned) continue;
+        const int n = min(cj->nev, EVCAP);
+        for (int e = tid; e < n && base + e < EVCAP; e += COMMIT_NT) { ev->key[base + e] = jb.evkey[(size_t)j * EVCAP + e]; ev->dl[base + e] = jb.evdl[(size_t)j * EVCAP + e]; }
+        base += n;
+    }
+    const int nev = min(base, EVCAP);
+    __syncthreads();
+    for (int e = tid; e < nev; e += COMMIT_NT) {                                   // rank sort (nev is small)
+        const int ke = ev->key[e];
+        int r = 0;
+        for (int f = 0; f < nev; ++f) { const int kf = ev->key[f]; r += (kf < ke || (kf == ke && f < e)) ? 1 : 0; }
+        ev->skey[r] = ke; ev->scum[r] = ev->dl[e];
     }
     __syncthreads();
-    PH_ADD(h, 3)
     if (tid == 0) {
-        const int oend = order[wayL], nend = aux[L - 1];
-        if (oend != nend) { st.tally[oend].endcnt -= 1; st.tally[nend].endcnt += 1; }
+        // running sums, and the segments of old ordinals that move: seg k = ordinals (after event k, up to event k+1]
+        int cum = 0, ns = 0, pre = 0;
+        for (int e = 0; e < nev; ++e) {
+            cum += ev->scum[e];
+            ev->scum[e] = cum;
+            const int lo_y = (ev->skey[e] >> 1) + 1;                               // first old ordinal after this event
+            const int hi_y = e + 1 < nev ? ((ev->skey[e + 1] & 1) ? (ev->skey[e + 1] >> 1) + 1 : (ev->skey[e + 1] >> 1)) : W;   // one past the last one before the next (a deleted column is not moved)
+            if (cum != 0 && hi_y > lo_y) { ev->seg_lo[ns] = lo_y; ev->seg_sh[ns] = cum; ev->seg_pre[ns] = pre; pre += hi_y - lo_y; ++ns; }
+        }
+        ev->seg_pre[ns] = pre;
+        ev->ns = ns; ev->cum = cum; ev->nev = nev;
     }
-    {
-        // the row is one piece from now on: its inner segment ends are no ends any more
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(COMMIT_NT) void k_commit_apply(DState st, JobBufs jb, int njobs)
+{
+    __shared__ BatchPlan sp;
+    __shared__ CommitEv ev;
+    const int tid = threadIdx.x;
+    if (tid == 0) commit_decide(st, jb, njobs, &sp);
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = tid; i < (int)(sizeof(BatchPlan) / 4); i += COMMIT_NT) reinterpret_cast<int *>(jb.plan)[i] = reinterpret_cast<const int *>(&sp)[i];
+    if (sp.idle || sp.ncommit == 0) return;
+    const Hdr *h = st.hdr;
+    const int W = h->W;
+    const int *order = cur_order(st);
+    const int nfree = h->nfree, nslots = h->nslots;
+    const int take = min(sp.nnew, nfree);
+    const int gt = (int)blockIdx.x * COMMIT_NT + tid, GT = (int)gridDim.x * COMMIT_NT;
+    for (int t = 0; t < sp.ncommit; ++t) {
+        const int job = sp.cjobs[t];
+        const JobMeta *m = &jb.meta[job];
+        const CommitJob *cj = &jb.cjob[job];
+        if (!cj->scanned) continue;                                                // every base stays where it was
+        const int k = m->k, L = m->L;
+        const long long off = st.rowoff[k];
+        const int *way = jb.way + (size_t)job * jb.Lmax;
+        const int *newcol = jb.newcol + (size_t)job * jb.Lmax;
+        int *aux = jb.aux + (size_t)job * jb.Lmax;
+        const int *insidx = jb.insidx + (size_t)job * jb.Lmax;
+        // 1. new columns (PW:1245-1332: the row's base, and AlGapCount on every entry but the gaps', PW:1320-1325) and the slot of
+        //    every base (into `pos` at once: nothing else reads this row's)
+        for (int x = gt; x < L; x += GT) {
+            const int c = newcol[x];
+            const int y = c >> 1;
+            int slot = order[y];
+            if (c & 1) {
+                const int idx = sp.slotbase[t] + insidx[x];
+                slot = (idx < take) ? st.freelist[nfree - 1 - idx] : nslots + (idx - take);
+                const int bs = (int)st.seq[off + x];
+                const uint32_t al = (uint32_t)aux[x];
+                Tally nt;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) nt.w[b] = ((b != bs) ? 1u : 0u) + ((b != 4) ? al : 0u);
+                nt.endcnt = (x == L - 1) ? 1u : 0u; nt.pad = 0;
+                st.tally[slot] = nt;
+                atomicAdd(&st.inscnt[y], 1);
+            }
+            aux[x] = slot;
+            st.pos[off + x] = slot;
+            if (x == L - 1) {
+                const int oend = order[way[L - 1]];
+                if (oend != slot) { atomicSub(&st.tally[oend].endcnt, 1u); if (!(c & 1)) atomicAdd(&st.tally[slot].endcnt, 1u); }
+            }
+        }
+        // 2. Columns_Downdater + Column_Updater fused (PW:1172-1243) for the columns whose symbol for this row changes (the six
+        //    tallies only: the ends' count of the same record is kept by atomics)
+        const int nchg = cj->nchg;
+        const int *list = jb.chg + (size_t)job * jb.colcap;
+        for (int i = gt; i < nchg; i += GT) {
+            const int e_ = list[i];
+            const int y = e_ & 0xffffff, so = (e_ >> 24) & 15, sn = (e_ >> 28) & 15;
+            Tally *tp = &st.tally[order[y]];
+            const uint4 a = *reinterpret_cast<const uint4 *>(&tp->w[0]);
+            const uint2 b2 = *reinterpret_cast<const uint2 *>(&tp->w[4]);
+            uint32_t w[6] = {a.x, a.y, a.z, a.w, b2.x, b2.y};
+#pragma unroll
+            for (int b = 0; b < 6; ++b) w[b] = w[b] - ((so != 5 && b != so) ? 1u : 0u) + ((sn != 5 && b != sn) ? 1u : 0u);
+            *reinterpret_cast<uint4 *>(&tp->w[0]) = make_uint4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<uint2 *>(&tp->w[4]) = make_uint2(w[4], w[5]);
+        }
+        // the row is one piece from now on: its inner segment ends are no ends any more (nbrk[k] is cleared by the finish)
         const int nb = st.nbrk[k];
         const int *bx = st.brkx + st.brkoff[k];
-        for (int t = tid; t < nb; t += COMMIT_NT) atomicSub(&st.tally[order[way[bx[t]]]].endcnt, 1u);
-        __syncthreads();
-        if (tid == 0 && nb) st.nbrk[k] = 0;
+        for (int i = gt; i < nb; i += GT) atomicSub(&st.tally[order[way[bx[i]]]].endcnt, 1u);
     }
-    PH_ADD(h, 4)
-    const bool restructure = (nnew > 0) || (s_i[1] != 0);
-    const int nev = s_i[5];
-    const bool inplace = restructure && nev <= jb.evcap;
-    int Wnew = W;
-    if (inplace) {
-        // 3a. W_Con (PW:706-763) + splice, the usual case: a handful of columns opened or emptied.  Only the ordinals between
-        //     events whose shifts do not cancel move -- a row that trades a column for its neighbour at either end (what
-        //     every realignment of a converged MSA does) touches a few entries, not the width.  Events are sorted by
-        //     position (key 2y: column y is deleted, 2y+1: a column opens after y); an old ordinal y moves by the sum of the
-        //     events with key < 2y; the moves go through a scratch copy because source and target ranges overlap.
-        for (int e = tid; e < nev; e += COMMIT_NT) {                               // rank sort (nev is small)
-            const int ke = ev->key[e];
-            int r = 0;
-            for (int f = 0; f < nev; ++f) { const int kf = ev->key[f]; r += (kf < ke || (kf == ke && f < e)) ? 1 : 0; }
-            ev->skey[r] = ke; ev->scum[r] = ev->dl[e];
-        }
-        __syncthreads();
+    if (!sp.restructure || sp.big) return;
+    // 3. W_Con (PW:706-763) + splice, first half: the stretches that move go out to a scratch array (source and target ranges
+    //    overlap); k_commit_finish brings them back under their new ordinals.  Every work-group sorts the events for itself.
+    commit_sort_events(jb, &sp, W, &ev);
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < (int)(sizeof(CommitEv) / 4); i += COMMIT_NT) reinterpret_cast<int *>(jb.sev)[i] = reinterpret_cast<const int *>(&ev)[i];
+        // the slots of the emptied columns, read before anything moves
         if (tid == 0) {
-            // running sums, and the segments of old ordinals that move: seg k = ordinals (after event k, up to event k+1]
-            int cum = 0, ns = 0, pre = 0;
-            for (int e = 0; e < nev; ++e) {
-                cum += ev->scum[e];
-                ev->scum[e] = cum;
-                const int lo_y = (ev->skey[e] >> 1) + 1;                            // first old ordinal after this event
-                const int hi_y = e + 1 < nev ? ((ev->skey[e + 1] & 1) ? (ev->skey[e + 1] >> 1) + 1 : (ev->skey[e + 1] >> 1)) : W;   // one past the last one before the next (a deleted column is not moved)
-                if (cum != 0 && hi_y > lo_y) { ev->seg_lo[ns] = lo_y; ev->seg_sh[ns] = cum; ev->seg_pre[ns] = pre; pre += hi_y - lo_y; ++ns; }
-            }
-            ev->seg_pre[ns] = pre;
-            s_i[6] = ns; s_i[7] = cum;
+            int pfree = 0;
+            for (int e = 0; e < ev.nev; ++e) if (!(ev.skey[e] & 1)) jb.freed[pfree++] = order[ev.skey[e] >> 1];
         }
+    }
+    const int ns = ev.ns, total = ev.seg_pre[ns];
+    int *tmp = st.newidx;
+    auto seg_of = [&](int i) { int a = 0, b = ns - 1; while (a < b) { const int mid = (a + b + 1) >> 1; if (ev.seg_pre[mid] <= i) a = mid; else b = mid - 1; } return a; };
+    for (int i = gt; i < total; i += GT) { const int sgi = seg_of(i); tmp[i] = order[ev.seg_lo[sgi] + (i - ev.seg_pre[sgi])]; }
+}
+
+// The header as it stands after a batch goes to pinned host memory straight from the commit: every word but the sequence
+// number, a system-scope fence, then the number -- the host polls that word, no copy command and no event record (6 us each
+// on the stream) behind every batch.
+__device__ __forceinline__ void publish_header(const Hdr *h, Hdr *host_copy, unsigned seq)
+{
+    if (!host_copy) return;
+    constexpr int NWORDS = (int)(sizeof(Hdr) / 4), SEQW = (int)(offsetof(Hdr, seq) / 4);
+    if ((int)threadIdx.x < NWORDS && (int)threadIdx.x != SEQW) reinterpret_cast<volatile int *>(host_copy)[threadIdx.x] = reinterpret_cast<const int *>(h)[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) { *reinterpret_cast<volatile unsigned *>(&host_copy->seq) = seq; __threadfence_system(); }
+}
+
+// Second half of the renumbering, then -- by the work-group that arrives last, when every other one has finished -- the header:
+// the width, the k loop's row pointer (PW:1695 lives on the device), the size of the next batch.  A batch costs as long as its
+// longest fill, and rows that overlap the rows before them are almost always invalidated while the MSA is still moving, so
+// speculate just past the running mean of rows committed per batch -- and never let a speculative row make the batch longer than
+// its first row, the only one that is certain to commit.
+__global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs jb, int njobs, const int *rowids, Hdr *host_copy, unsigned host_seq)
+{
+    __shared__ unsigned sh[COMMIT_NT / 64];
+    __shared__ int s_skey[EVCAP], s_scum[EVCAP], s_seg_lo[EVCAP + 1], s_seg_sh[EVCAP + 1], s_seg_pre[EVCAP + 2];
+    __shared__ int s_last, s_free, s_w;
+    const int tid = threadIdx.x;
+    Hdr *h = st.hdr;
+    const BatchPlan *p = jb.plan;
+    const int W = h->W, cur = h->cur;
+    const int *order = cur ? st.order1 : st.order0;
+    int *norder = cur ? st.order0 : st.order1;
+    const int nfree = h->nfree, nslots = h->nslots;
+    const int take = min(p->nnew, nfree);
+    const int gt = (int)blockIdx.x * COMMIT_NT + tid, GT = (int)gridDim.x * COMMIT_NT;
+    int Wnew = W;
+    if (!p->idle && p->restructure && !p->big) {
+        const CommitEv *ev = jb.sev;
+        const int nev = ev->nev, ns = ev->ns;
+        for (int i = tid; i < nev; i += COMMIT_NT) { s_skey[i] = ev->skey[i]; s_scum[i] = ev->scum[i]; }
+        for (int i = tid; i <= ns; i += COMMIT_NT) { s_seg_lo[i] = ev->seg_lo[i]; s_seg_sh[i] = ev->seg_sh[i]; s_seg_pre[i] = ev->seg_pre[i]; }
         __syncthreads();
-        const int ns = s_i[6], total = ev->seg_pre[ns];
-        int *tmp = st.newidx;
-        // freed slots (read before anything moves) and the scratch copy of what moves
-        for (int e = tid; e < nev; e += COMMIT_NT)
-            if (!(ev->skey[e] & 1)) { const int p = atomicAdd(&s_i[0], 1); st.freelist[nfree - take + p] = order[ev->skey[e] >> 1]; }
+        const int total = s_seg_pre[ns];
+        const int *tmp = st.newidx;
         int *ordw = const_cast<int *>(order);
-        if (ns <= 24) {
-            // a few long stretches (one column more or less shifts everything behind it): plain copy loops, four entries in flight
-            for (int sgi = 0; sgi < ns; ++sgi) {
-                const int *src = order + ev->seg_lo[sgi];
-                int *dst = tmp + ev->seg_pre[sgi];
-                const int n_ = ev->seg_pre[sgi + 1] - ev->seg_pre[sgi];
-                int i = tid;
-                for (; i + 3 * COMMIT_NT < n_; i += 4 * COMMIT_NT) {
-                    const int v0 = src[i], v1 = src[i + COMMIT_NT], v2 = src[i + 2 * COMMIT_NT], v3 = src[i + 3 * COMMIT_NT];
-                    dst[i] = v0; dst[i + COMMIT_NT] = v1; dst[i + 2 * COMMIT_NT] = v2; dst[i + 3 * COMMIT_NT] = v3;
+        auto seg_of = [&](int i) { int a = 0, b = ns - 1; while (a < b) { const int mid = (a + b + 1) >> 1; if (s_seg_pre[mid] <= i) a = mid; else b = mid - 1; } return a; };
+        for (int i = gt; i < total; i += GT) {
+            const int sgi = seg_of(i);
+            const int yn = s_seg_lo[sgi] + (i - s_seg_pre[sgi]) + s_seg_sh[sgi];
+            const int slot = tmp[i];
+            ordw[yn] = slot; st.rank[slot] = yn;
+        }
+        // the new columns: after old ordinal y, before any column opened there by a later base of the same row (PW:1245-1332)
+        for (int t = 0; t < p->ncommit; ++t) {
+            const int job = p->cjobs[t];
+            if (!jb.cjob[job].scanned || jb.meta[job].nnew == 0) continue;
+            const int L = jb.meta[job].L;
+            const int *newcol = jb.newcol + (size_t)job * jb.Lmax;
+            const int *aux = jb.aux + (size_t)job * jb.Lmax;
+            for (int x = gt; x < L; x += GT) {
+                const int c = newcol[x];
+                if (c & 1) {
+                    const int y = c >> 1;
+                    int tt = 0;
+                    for (int xx = x - 1; xx >= 0 && newcol[xx] == c; --xx) ++tt;   // earlier bases opened there too
+                    int a = 0, b = nev;                                             // events with key < 2y
+                    while (a < b) { const int mid = (a + b) >> 1; if (s_skey[mid] < 2 * y) a = mid + 1; else b = mid; }
+                    const int shy = a ? s_scum[a - 1] : 0;
+                    const int kept = (a < nev && s_skey[a] == 2 * y) ? 0 : 1;       // y itself emptied by this batch?
+                    const int pnew = y + shy + kept + tt;
+                    ordw[pnew] = aux[x]; st.rank[aux[x]] = pnew;
+                    st.inscnt[y] = 0;
                 }
-                for (; i < n_; i += COMMIT_NT) dst[i] = src[i];
-            }
-            __threadfence_block();
-            __syncthreads();
-            for (int sgi = 0; sgi < ns; ++sgi) {
-                const int *src = tmp + ev->seg_pre[sgi];
-                const int y0_ = ev->seg_lo[sgi] + ev->seg_sh[sgi];
-                const int n_ = ev->seg_pre[sgi + 1] - ev->seg_pre[sgi];
-                int i = tid;
-                for (; i + 3 * COMMIT_NT < n_; i += 4 * COMMIT_NT) {
-                    const int v0 = src[i], v1 = src[i + COMMIT_NT], v2 = src[i + 2 * COMMIT_NT], v3 = src[i + 3 * COMMIT_NT];
-                    ordw[y0_ + i] = v0; ordw[y0_ + i + COMMIT_NT] = v1; ordw[y0_ + i + 2 * COMMIT_NT] = v2; ordw[y0_ + i + 3 * COMMIT_NT] = v3;
-                    st.rank[v0] = y0_ + i; st.rank[v1] = y0_ + i + COMMIT_NT; st.rank[v2] = y0_ + i + 2 * COMMIT_NT; st.rank[v3] = y0_ + i + 3 * COMMIT_NT;
-                }
-                for (; i < n_; i += COMMIT_NT) { const int v = src[i]; ordw[y0_ + i] = v; st.rank[v] = y0_ + i; }
-            }
-        } else {
-            auto seg_of = [&](int i) { int a = 0, b = ns - 1; while (a < b) { const int mid = (a + b + 1) >> 1; if (ev->seg_pre[mid] <= i) a = mid; else b = mid - 1; } return a; };
-            for (int i = tid; i < total; i += COMMIT_NT) { const int sgi = seg_of(i); tmp[i] = order[ev->seg_lo[sgi] + (i - ev->seg_pre[sgi])]; }
-            __threadfence_block();
-            __syncthreads();
-            for (int i = tid; i < total; i += COMMIT_NT) {
-                const int sgi = seg_of(i);
-                const int yn = ev->seg_lo[sgi] + (i - ev->seg_pre[sgi]) + ev->seg_sh[sgi];
-                const int slot = tmp[i];
-                ordw[yn] = slot; st.rank[slot] = yn;
             }
         }
-        // the new columns: after old ordinal y, before any column opened there by a later base of this row (PW:1245-1332)
-        for (int x = tid; x < L; x += COMMIT_NT) {
-            const int c = newcol[x];
-            if (c & 1) {
-                const int y = c >> 1;
-                int t = 0;
-                for (int xx = x - 1; xx >= 0 && newcol[xx] == c; --xx) ++t;        // earlier bases opened there too
-                int a = 0, b = nev;                                                 // events with key < 2y
-                while (a < b) { const int mid = (a + b) >> 1; if (ev->skey[mid] < 2 * y) a = mid + 1; else b = mid; }
-                const int shy = a ? ev->scum[a - 1] : 0;
-                const int kept = (a < nev && ev->skey[a] == 2 * y) ? 0 : 1;         // y itself emptied by this commit?
-                const int pnew = y + shy + kept + t;
-                ordw[pnew] = aux[x]; st.rank[aux[x]] = pnew;
-                st.inscnt[y] = 0;
-            }
-        }
-        Wnew = W + s_i[7];
-    } else if (restructure) {
-        // 3b. the same by a pass over the width (more than EVCAP events): new ordinal of every surviving / new column.  Columns
-        //    left of the first one that changes keep their ordinal, and the other order buffer already holds them as far as
-        //    the two agree, so the renumbering starts there
-        const int s0 = max(0, min(s_i[4], h->agree));
-        carry = (unsigned)s0;
+        if (blockIdx.x == 0) for (int i = tid; i < p->ndel; i += COMMIT_NT) st.freelist[nfree - take + i] = jb.freed[i];
+        Wnew = W + ev->cum;
+    } else if (!p->idle && p->restructure && blockIdx.x == 0) {
+        // the same by a pass over the width (more than evcap events; one work-group): new ordinal of every surviving / new column.
+        // Columns left of the first one that changes keep their ordinal, and the other order buffer already holds them as far
+        // as the two agree, so the renumbering starts there
+        if (tid == 0) s_free = 0;
+        __syncthreads();
+        const int s0 = max(0, min(p->first, h->agree));
+        unsigned carry = (unsigned)s0;
         for (int base = s0; base < W; base += COMMIT_NT) {
             const int y = base + tid;
             const bool valid = y < W;
@@ -3186,238 +3394,110 @@ __device__ void commit_job(const DState &st, const JobBufs &jb, int job, unsigne
             if (valid) {
                 st.newidx[y] = idx;
                 if (keep) { norder[idx] = slot; st.rank[slot] = idx; }
-                else { const int p = atomicAdd(&s_i[0], 1); st.freelist[nfree - take + p] = slot; }
+                else { const int q = atomicAdd(&s_free, 1); st.freelist[nfree - take + q] = slot; }
                 if (ic) st.inscnt[y] = 0;
             }
         }
         __syncthreads();
-        for (int x = tid; x < L; x += COMMIT_NT) {
-            const int c = newcol[x];
-            if (c & 1) {
-                const int y = c >> 1;
-                int t = 0;
-                for (int xx = x - 1; xx >= 0 && newcol[xx] == c; --xx) ++t;    // earlier bases opened there too
-                const int keepy = st.tally[order[y]].w[4] != 0 ? 1 : 0;
-                const int p = st.newidx[y] + keepy + t;
-                norder[p] = aux[x];
-                st.rank[aux[x]] = p;
+        for (int t = 0; t < p->ncommit; ++t) {
+            const int job = p->cjobs[t];
+            if (!jb.cjob[job].scanned || jb.meta[job].nnew == 0) continue;
+            const int L = jb.meta[job].L;
+            const int *newcol = jb.newcol + (size_t)job * jb.Lmax;
+            const int *aux = jb.aux + (size_t)job * jb.Lmax;
+            for (int x = tid; x < L; x += COMMIT_NT) {
+                const int c = newcol[x];
+                if (c & 1) {
+                    const int y = c >> 1;
+                    int tt = 0;
+                    for (int xx = x - 1; xx >= 0 && newcol[xx] == c; --xx) ++tt;
+                    const int keepy = st.tally[order[y]].w[4] != 0 ? 1 : 0;
+                    const int q = st.newidx[y] + keepy + tt;
+                    norder[q] = aux[x];
+                    st.rank[aux[x]] = q;
+                }
             }
         }
-        Wnew = (int)carry;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        if (restructure) {
-            h->W = Wnew;
-            h->nslots = nslots + (nnew - take);
-            h->nfree = nfree - take + s_i[0];
-            if (inplace) h->agree = max(0, min(h->agree, min(s_i[4], W)));         // the other buffer was left alone
-            else { h->cur = cur ^ 1; h->agree = max(0, min(s_i[4], W)); }
-        }
-        h->version = (int)newver;
-        h->cells_reference += m->cells;
-        if (s_i[3] || nnew > 0) h->rows_changed += 1;
-    }
-    __syncthreads();
-    PH_ADD(h, 5)
-#ifdef PWR_DIAG
-    if (tid == 0) { h->dbg[6] += 1; h->dbg[7] += (unsigned long long)nev; h->dbg[8] += inplace ? 1 : 0; }
-#endif
-}
-
-// Is a speculatively computed job still exact?  Its DP inputs are: the tallies of the columns
-// lo..hi (row removed), their order, the row's own placement, and the distances to both MSA edges
-// where a clamp (PW:1496-1497, PW:1505) is active.  They are unchanged iff both end columns are still
-// alive and as far apart as before, no column in between carries a newer version, and the edge
-// distances that matter are the same.  On success the job's ordinals are shifted to today's numbering.
-__device__ bool validate_job(const DState &st, const JobBufs &jb, int job, unsigned *sh, int *s_i)
-{
-    const int tid = threadIdx.x;
-    Hdr *h = st.hdr;
-    JobMeta *m = &jb.meta[job];
-    const int W = h->W;
-    const int *order = h->cur ? st.order1 : st.order0;
-    const int L = m->L;
-    int *way = jb.way + (size_t)job * jb.Lmax;
-    int *newcol = jb.newcol + (size_t)job * jb.Lmax;
-    if (m->ver == h->version) return true;                     // nothing committed since the gather
-    PH_T0()
-    const int lo = m->lo, hi = m->hi;
-    const int lo2 = st.rank[m->slot_lo], hi2 = st.rank[m->slot_hi];
-    bool ok = lo2 >= 0 && lo2 < W && hi2 >= 0 && hi2 < W;
-    ok = ok && order[lo2] == m->slot_lo && order[hi2] == m->slot_hi && (hi2 - lo2) == (hi - lo);
-    int why = ok ? -1 : 0;
-    const int d = lo2 - lo;
-    if (ok) {
-        const int way0 = way[0], wayL = way[L - 1], H = st.H, B = st.B;
-        if (d != 0 && !(way0 - H >= 1 && way0 + d - H >= 1)) { ok = false; why = 1; }           // left clamp PW:1496
-        const int aL = max(0, wayL - H);
-        const bool far_old = aL + B <= m->W - 1, far_new = aL + d + B <= W - 1;
-        if (ok && !(far_old && far_new) && (W - hi2) != (m->W - hi)) { ok = false; why = 2; }   // right clamp PW:1497/1505
-    }
-    unsigned mx = 0;
-    if (ok) for (int y = lo2 + tid; y <= hi2; y += COMMIT_NT) mx = max(mx, st.colver[order[y]]);
-    mx = ~block_min_u32<COMMIT_NT>(~mx, sh);
-    if (ok && mx > (unsigned)m->ver) { ok = false; why = 3; }
-    if (tid == 0 && why >= 0) st.hdr->fail_reason[why] += 1;
-    if (tid == 0) s_i[2] = ok ? 1 : 0;
-    __syncthreads();
-    ok = s_i[2] != 0;
-    if (ok && d != 0) {
-        for (int x = tid; x < L; x += COMMIT_NT) { way[x] += d; newcol[x] += 2 * d; }
+        if (tid == 0) s_w = (int)carry;
         __syncthreads();
-        if (tid == 0) { m->lo = lo + d; m->hi = hi + d; }
+        Wnew = s_w;
+        if (tid == 0) jb.sev->cum = Wnew - W;                                      // (for the work-group that writes the header)
     }
-    if (ok && tid == 0) m->W = W;
+    // ---- the last work-group to get here writes the header
     __syncthreads();
-    PH_ADD(h, 0)
-#ifdef PWR_DIAG
-    if (tid == 0) h->dbg[9] += 1;
-#endif
-    return ok;
-}
-
-// Commit the jobs of a batch in row order; stop at the first one whose inputs have changed.  Then move the row pointer on
-// and size the next batch: a batch costs as long as its longest fill, and rows that overlap the rows before them are almost
-// always invalidated while the MSA is still moving, so speculate just past the running mean of rows committed per batch --
-// and never let a speculative row make the batch longer than its first row, the only one that is certain to commit (a fill
-// takes time proportional to the row's length).
-// The header as it stands after a batch goes to pinned host memory straight from the commit kernel: every word but the
-// sequence number, a system-scope fence, then the number -- the host polls that word, no copy command and no event record
-// (6 us each on the stream) behind every batch.
-__device__ __forceinline__ void publish_header(const Hdr *h, Hdr *host_copy, unsigned seq)
-{
-    if (!host_copy) return;
-    constexpr int NWORDS = (int)(sizeof(Hdr) / 4), SEQW = (int)(offsetof(Hdr, seq) / 4);
-    if ((int)threadIdx.x < NWORDS && (int)threadIdx.x != SEQW) reinterpret_cast<volatile int *>(host_copy)[threadIdx.x] = reinterpret_cast<const int *>(h)[threadIdx.x];
-    __threadfence_system();
+    if (tid == 0) { __threadfence(); s_last = atomicAdd(jb.ticket, 1u) == gridDim.x - 1 ? 1 : 0; }
     __syncthreads();
-    if (threadIdx.x == 0) { *reinterpret_cast<volatile unsigned *>(&host_copy->seq) = seq; __threadfence_system(); }
-}
-
-__global__ __launch_bounds__(COMMIT_NT) void k_commit_chain(DState st, JobBufs jb, int njobs, const int *rowids, Hdr *host_copy, unsigned host_seq)
-{
-    __shared__ unsigned sh[COMMIT_NT / 64];
-    __shared__ int s_i[12];
-    __shared__ CommitEv evs;
-    Hdr *h = st.hdr;
-#ifdef PWR_DIAG
-    const unsigned long long ph_chain0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    if (threadIdx.x == 0) { h->ncommitted = 0; h->stop = 0; }
-    __syncthreads();
-    if (h->status != 0 || h->need_grow) {
-        publish_header(h, host_copy, host_seq);
-        return;
-    }
-    // Jobs in row order.  A stale job (its inputs were changed by a commit since the gather) is left for the next batch --
-    // and a later job may still commit AHEAD of it when the two commute: their band intervals [lo, hi] (every column either
-    // DP reads or either commit writes) are disjoint, with a margin for the column a commit may open at its interval's edge.
-    // The DP depends on absolute positions only through the clamps at the MSA's edges, which disjoint intervals rule out
-    // (commutation probe), so realigning j after i gives the state the reference reaches with j before i.
-    __shared__ int sk_row[128];                                                   // rows of the stale jobs
-    int live_done = 0, live_all = 0, nskip = 0, ahead_n = 0;
-    unsigned long long done_mask = 0;
-    bool stopped = false;
-    for (int j = 0; j < njobs; ++j) {
-        JobMeta *m = &jb.meta[j];
-        if (!m->active) break;                                                    // the batch ends here
-        if (m->L > 0) {
-            live_all += 1;
-            if (stopped) continue;
-            if (!m->ok) { stopped = true; continue; }                             // status already set
-            // room for the columns this commit may open?  (host regrows the arrays and the batch is repeated)
-            if ((long long)h->W + m->L + 64 > st.colcap || (long long)h->nslots + m->L + 64 > st.slotcap) {
-                if (threadIdx.x == 0) h->need_grow = 1;
-                stopped = true;
-                continue;
-            }
-            if (m->wide && !jb.f64_follows) { stopped = true; continue; }         // (its batch came without k_fill64: the next ones bring it)
-            if (m->abort) {
-                // k_fill_v3 gave this job up (time-out): it is realigned again, by k_fill_v2, as are the next batches
-                if (threadIdx.x == 0) {
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) {
+        *jb.ticket = 0u;
+        h->ncommitted = 0; h->stop = 0;
+        if (!p->idle) {
+            int version = h->version;
+            for (int j = 0; j < njobs && j < MAXJ; ++j) {
+                const int v = p->verdict[j];
+                if (v == V_NONE) break;
+                JobMeta *m = &jb.meta[j];
+                if (v == V_STOP_GROW) h->need_grow = 1;
+                else if (v == V_STOP_ABORT) {
+                    // k_fill_v3 gave this job up (time-out): it is realigned again, by k_fill_v2, as are the next batches
                     h->stalls += 1;
                     if (jb.wpNW <= 16) h->fallback = 65; else atomicCAS(&h->status, 0, PWR_ERR_STALL);   // (no one-work-group form of 17 waves)
-                }
-                stopped = true;
-                continue;
-            }
-            if (m->segfail) {
-                // a segment of its fill had not forgotten its start when its own rows began (k_seg_check): the row is
-                // realigned again, its fill in one piece
-                if (threadIdx.x == 0) {
+                } else if (v == V_STOP_SEGFAIL) {
+                    // a segment of its fill had not forgotten its start when its own rows began (k_seg_check): the row is
+                    // realigned again, with the longest warm-up, then in one piece
                     h->seg_fails += 1; h->noseg_level = h->noseg_row == m->k ? h->noseg_level + 1 : 1; h->noseg_row = m->k;
                     if (h->noseg_level == 1 && h->warm_step > 0) h->warm_cur = min(h->warm_hi, h->warm_cur + h->warm_up);
-                }
-                stopped = true;
-                continue;
-            }
-            bool good = validate_job(st, jb, j, sh, s_i);                         // (on success lo / hi are in today's numbering)
-            if (good && nskip > 0) {
-                // The interval a stale row WILL be realigned over is the one its next gather takes from the state as it is
-                // now (the columns its gather of this batch saw at the interval's ends may since have moved against its
-                // bases: an earlier commit of the batch opened or emptied columns in between).  A commit of a disjoint
-                // interval only renumbers it.
-                const int Wn = h->W;
-                for (int t = 0; t < nskip && good; ++t) {
-                    const int ks = sk_row[t], Ls = st.rowlen[ks];
-                    const long long offs = st.rowoff[ks];
-                    const int w0 = st.rank[st.pos[offs]], wL = st.rank[st.pos[offs + Ls - 1]];
-                    const int lo_s = max(0, max(0, w0 - st.H) - 1), hi_s = min(Wn - 1, max(0, wL - st.H) + st.B - 1);
-                    if (!(m->hi + 2 < lo_s || hi_s + 2 < m->lo)) good = false;
+                } else if (v == V_STALE) h->stop = 1;
+                else if (v == V_COMMIT) {
+                    const CommitJob *cj = &jb.cjob[j];
+                    if (cj->scanned) {
+                        version += 1;
+                        if (cj->nchg > 0 || m->nnew > 0) h->rows_changed += 1;
+                        if (st.nbrk[m->k]) st.nbrk[m->k] = 0;
+                    }
+                    h->cells_reference += m->cells;
+                    if (h->noseg_row == m->k) { h->noseg_row = -1; h->noseg_level = 0; }
+                    else if (m->nseg > 1) h->warm_cur = max(h->warm_lo, h->warm_cur - h->warm_step);
+                    if (m->wide) h->rows_wide += 1;
                 }
             }
-            if (!good) {
-                if (threadIdx.x == 0) h->stop = 1;
-                if (nskip >= 128) { stopped = true; continue; }
-                if (threadIdx.x == 0) sk_row[nskip] = m->k;
-                nskip += 1;
-                __syncthreads();
-                continue;
+            h->version = version;
+            for (int i = 0; i < 4; ++i) h->fail_reason[i] += (unsigned long long)p->reasons[i];
+            if (p->restructure) {
+                const int cum = jb.sev->cum;
+                h->W = W + cum;
+                h->nslots = nslots + (p->nnew - take);
+                h->nfree = nfree - take + p->ndel;
+                if (!p->big) h->agree = max(0, min(h->agree, min(p->first, W)));   // the other buffer was left alone
+                else { h->cur = cur ^ 1; h->agree = max(0, min(p->first, W)); }
             }
-            commit_job(st, jb, j, sh, s_i, &evs);
-            if (threadIdx.x == 0) {
-                if (h->noseg_row == m->k) { h->noseg_row = -1; h->noseg_level = 0; }
-                else if (m->nseg > 1) h->warm_cur = max(h->warm_lo, h->warm_cur - h->warm_step);
+            const unsigned long long dm = h->ahead | p->done_mask;
+            const int adv = ~dm ? __builtin_ctzll(~dm) : 64;
+            const int done = __builtin_popcountll(p->done_mask);
+            h->ncommitted = done;
+            h->next_row += adv;
+            h->ahead = adv >= 64 ? 0ull : dm >> adv;
+            h->rows_ahead += (unsigned long long)p->ahead_n;
+            if (h->fallback > 0 && jb.v2_follows) h->fallback -= 1;
+            if (h->need64 > 0 && jb.f64_follows) h->need64 -= 1;
+            if (p->live_all > 0) h->batches += 1;
+            h->rows_committed += (unsigned long long)p->live_done;
+            h->rows_recomputed += (unsigned long long)(p->live_all - p->live_done);
+            if (h->status == 0 && !h->need_grow && done > 0) {
+                const float ema = 0.75f * h->ema + 0.25f * (float)done;
+                h->ema = ema;
+                const int k = h->next_row, left = h->row_end - k;
+                int nb = (int)(ema + 2.6f);
+                nb = max(1, min(nb, min(h->window, left)));
+                if (left > 0) {
+                    const int l0 = st.rowlen[rowids[k]];
+                    for (int j = 1; j < nb; ++j)
+                        if (st.rowlen[rowids[k + j]] > l0 + (int)((long long)l0 * h->speclen / 100) + 64) { nb = j; break; }
+                }
+                h->nb = nb;
             }
-            live_done += 1;
-            if (nskip > 0) ahead_n += 1;
-            if (m->wide && threadIdx.x == 0) h->rows_wide += 1;
         }
-        // (a row without bases, PW:1488, is done wherever it stands)
-        if (m->off < 64) done_mask |= 1ull << m->off; else stopped = true;
-        __syncthreads();
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long dm = h->ahead | done_mask;
-        const int adv = ~dm ? __builtin_ctzll(~dm) : 64;
-        const int done = __builtin_popcountll(done_mask);
-        h->ncommitted = done;
-        h->next_row += adv;
-        h->ahead = adv >= 64 ? 0ull : dm >> adv;
-        h->rows_ahead += (unsigned long long)ahead_n;
-        if (h->fallback > 0 && jb.v2_follows) h->fallback -= 1;
-        if (h->need64 > 0 && jb.f64_follows) h->need64 -= 1;
-        if (live_all > 0) h->batches += 1;
-        h->rows_committed += (unsigned long long)live_done;
-        h->rows_recomputed += (unsigned long long)(live_all - live_done);
-        if (h->status == 0 && !h->need_grow && done > 0) {
-            const float ema = 0.75f * h->ema + 0.25f * (float)done;
-            h->ema = ema;
-            const int k = h->next_row, left = h->row_end - k;
-            int nb = (int)(ema + 2.6f);
-            nb = max(1, min(nb, min(h->window, left)));
-            if (left > 0) {
-                const int l0 = st.rowlen[rowids[k]];
-                for (int j = 1; j < nb; ++j)
-                    if (st.rowlen[rowids[k + j]] > l0 + (int)((long long)l0 * h->speclen / 100) + 64) { nb = j; break; }
-            }
-            h->nb = nb;
-        }
-#ifdef PWR_DIAG
-        h->dbg[10] += __builtin_amdgcn_s_memrealtime() - ph_chain0; h->dbg[11] += 1;
-#endif
     }
     __threadfence();
     __syncthreads();
@@ -3505,11 +3585,12 @@ __global__ __launch_bounds__(256) void k_score(DState st, unsigned long long *ou
 }
 
 // MMA_Auslesen (PW:1556-1598): one work-group per row writes "ACGT- " text
-__global__ __launch_bounds__(256) void k_export(DState st, unsigned char *out, int row0, int nrows, int W)
+__global__ __launch_bounds__(256) void k_export(DState st, unsigned char *out, int row0, int nrows, int W, int nl)
 {
     const int r = row0 + blockIdx.x;
     if (blockIdx.x >= nrows) return;
-    unsigned char *o = out + (size_t)blockIdx.x * W;
+    unsigned char *o = out + (size_t)blockIdx.x * (size_t)(W + nl);                    // nl 1: the row's line of the FILE (PW:1594)
+    if (nl && threadIdx.x == 0) o[W] = '\n';
     const int L = st.rowlen[r];
     const long long off = st.rowoff[r];
     for (int y = threadIdx.x; y < W; y += blockDim.x) o[y] = ' ';
@@ -3585,7 +3666,9 @@ struct pwr_ctx {
     int one_wg = 0;                       // k_fill_v3: the waves of a segment as one work-group (hand-over through LDS); 0: one work-group per wave
     int seg_rows = 160;                   // k_fill_v3: a DP is filled in segments of about this many rows, side by side (0: in one piece)
     int seg_align = 16;                   // ... whose own parts start at multiples of this many rows (16 / 32 / 64)
-    int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
+    int seg_max = SEG_MAX;                // ... at most this many per DP (<= SEG_MAX)
+    int seg_budget = 200;                 // ... and this many for all the jobs of a batch together, dealt by length (0: seg_rows rows each, whatever that gives)
+    int seg_minrows = 64;                 // ... none with fewer own rows than this
     int split_rank = 0, split_world = 1;  // pwr_split_*: this context is replica split_rank of split_world (one per GPU)
     int split_k0 = 0, split_kend = 0;     // ... rows of the slab in progress
     int src_start = 1;                    // ... from the column of the base before the warm-up's first row alone (0: from the free start)
@@ -3599,9 +3682,16 @@ struct pwr_ctx {
     size_t ev_used = 0;
     void *h_hdr = nullptr;                // pinned staging buffer for the device header
     void *h_ring = nullptr;               // pinned copies of the header, one per batch in flight
+    // pwr_snapshot_*: the file image of the state, copied out on a stream of its own (buffers kept between snapshots)
+    unsigned char *snap_dev = nullptr, *snap_host = nullptr;
+    size_t snap_cap = 0;
+    hipStream_t snap_stream = nullptr;
+    hipEvent_t snap_taken = nullptr, snap_done = nullptr;
+    bool snap_busy = false;
     // all device allocations, for cleanup
     std::vector<void *> allocs;
 };
+struct pwr_snapshot { pwr_ctx *c; int rows, width; size_t bytes; };
 
 // The host's passes over the text (1.8 GB at benchmark scale: parse, EntAlGapper, the first tallies) are row-parallel:
 // f(r0, r1, t) for contiguous shares of the rows on up to 16 threads.
@@ -3693,6 +3783,11 @@ static void free_device(pwr_ctx *c)
     if (c->h_ring) {
         (void)hipHostFree(c->h_ring); c->h_ring = nullptr;
     }
+    if (c->snap_stream) { (void)hipStreamSynchronize(c->snap_stream); (void)hipStreamDestroy(c->snap_stream); c->snap_stream = nullptr; }
+    if (c->snap_taken) { (void)hipEventDestroy(c->snap_taken); c->snap_taken = nullptr; }
+    if (c->snap_done) { (void)hipEventDestroy(c->snap_done); c->snap_done = nullptr; }
+    if (c->snap_host) { (void)hipHostFree(c->snap_host); c->snap_host = nullptr; }
+    c->snap_dev = nullptr; c->snap_cap = 0; c->snap_busy = false;                   // (snap_dev is in allocs)
     c->on_device = false;
 }
 
@@ -3798,6 +3893,8 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     if ((rc = dmalloc(c, &jb.lastM, (size_t)njobs * jb.NC))) return rc;
     jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
     jb.seg_align = c->seg_align;
+    jb.seg_budget = c->seg_budget; jb.seg_minrows = c->seg_minrows;
+    jb.rowids = c->d_rowids;
     jb.seg_rows = c->fill_mode == 4 ? c->seg_rows : 0;
     jb.src_start = c->src_start;
     jb.split_rank = c->split_rank; jb.split_world = c->split_world;
@@ -3822,6 +3919,20 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     if (hipMemsetAsync(jb.gtr, 0, (size_t)njobs * jb.trk * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     c->trace_epoch = 0;
     if ((rc = dmalloc(c, &c->d_jobrows, njobs))) return rc;
+    if ((rc = dmalloc(c, &jb.cjob, njobs))) return rc;
+    if ((rc = dmalloc(c, &jb.chg, (size_t)njobs * jb.colcap))) return rc;
+    if ((rc = dmalloc(c, &jb.evkey, (size_t)njobs * EVCAP))) return rc;
+    if ((rc = dmalloc(c, &jb.evdl, (size_t)njobs * EVCAP))) return rc;
+    if ((rc = dmalloc(c, &jb.insidx, (size_t)njobs * jb.Lmax))) return rc;
+    if ((rc = dmalloc(c, &jb.pair_cf, (size_t)njobs * njobs))) return rc;
+    if ((rc = dmalloc(c, &jb.pair_left, (size_t)njobs * njobs))) return rc;
+    if ((rc = dmalloc(c, &jb.plan, 1))) return rc;
+    if ((rc = dmalloc(c, &jb.sev, 1))) return rc;
+    if ((rc = dmalloc(c, &jb.freed, EVCAP))) return rc;
+    if ((rc = dmalloc(c, &jb.ticket, 4))) return rc;
+    if (hipMemsetAsync(jb.cjob, 0, sizeof(CommitJob) * njobs, c->stream) != hipSuccess || hipMemsetAsync(jb.pair_cf, 0, sizeof(int) * (size_t)njobs * njobs, c->stream) != hipSuccess ||
+        hipMemsetAsync(jb.pair_left, 0, sizeof(int) * (size_t)njobs * njobs, c->stream) != hipSuccess || hipMemsetAsync(jb.plan, 0, sizeof(BatchPlan), c->stream) != hipSuccess ||
+        hipMemsetAsync(jb.sev, 0, sizeof(CommitEv), c->stream) != hipSuccess || hipMemsetAsync(jb.ticket, 0, 16, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     if (hipMemset(jb.meta, 0, sizeof(JobMeta) * njobs) != hipSuccess) return PWR_ERR_DEVICE;
     c->njobs = njobs;
     return PWR_OK;
@@ -3832,6 +3943,7 @@ static void free_jobs(pwr_ctx *c)
     JobBufs &jb = c->jb;
     dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.g64); dfree(c, jb.gpart); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
     dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.seg); dfree(c, jb.chk); dfree(c, jb.gtr); dfree(c, jb.diag); dfree(c, c->d_jobrows);
+    dfree(c, jb.cjob); dfree(c, jb.chg); dfree(c, jb.evkey); dfree(c, jb.evdl); dfree(c, jb.insidx); dfree(c, jb.pair_cf); dfree(c, jb.pair_left); dfree(c, jb.plan); dfree(c, jb.sev); dfree(c, jb.freed); dfree(c, jb.ticket);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -3964,7 +4076,6 @@ static int upload(pwr_ctx *c)
     if ((rc = dmalloc(c, &st.freelist, st.slotcap))) return rc;
     if ((rc = dmalloc(c, &st.inscnt, st.colcap))) return rc;
     if ((rc = dmalloc(c, &st.newidx, st.colcap))) return rc;
-    if ((rc = dmalloc(c, &st.colver, st.slotcap))) return rc;
     if ((rc = dmalloc(c, &c->d_score, 1))) return rc;
     st.rowoff = d_rowoff; st.rowlen = d_rowlen; st.seq = d_seq;
     {
@@ -3989,7 +4100,6 @@ static int upload(pwr_ctx *c)
     HIPC(hipMemcpy(st.order0, ident.data(), sizeof(int) * W, hipMemcpyHostToDevice));
     HIPC(hipMemcpy(st.rank, ident.data(), sizeof(int) * W, hipMemcpyHostToDevice));
     HIPC(hipMemset(st.inscnt, 0, sizeof(int) * st.colcap));
-    HIPC(hipMemset(st.colver, 0, sizeof(unsigned) * st.slotcap));
     {
         std::vector<int> ids(T);
         for (int r = 0; r < T; ++r) ids[r] = r;
@@ -4048,7 +4158,6 @@ static int grow_state(pwr_ctx *c, long long growth)
     if ((rc = regrow(c, &st.order1, ocol, ncap))) return rc;
     if ((rc = regrow(c, &st.rank, oslot, ncap))) return rc;
     if ((rc = regrow(c, &st.freelist, oslot, ncap))) return rc;
-    if ((rc = regrow(c, &st.colver, oslot, ncap))) return rc;
     if ((rc = regrow(c, &st.inscnt, 0, ncap))) return rc;
     if ((rc = regrow(c, &st.newidx, 0, ncap))) return rc;
     st.colcap = (int)ncap; st.slotcap = (int)ncap;
@@ -4182,6 +4291,7 @@ static int enqueue_front(pwr_ctx *c)
     const int n = c->window;
     int rc;
     c->jb.gather_tag = ++c->gather_tag;
+    c->jb.rowids = c->d_rowids;
     c->jb.f64_follows = (c->seen_need64 > 0 || c->force64) ? 1 : 0;
     hipLaunchKernelGGL(k_gather_a, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids);
     hipLaunchKernelGGL(k_gather_c, dim3(n, GATHER_G + 1), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
@@ -4199,13 +4309,22 @@ static int enqueue_front(pwr_ctx *c)
     return PWR_OK;
 }
 
+// the commit of a batch: what changes (per job and share), who commits and the changes themselves, the renumbering and the header
+static int enqueue_commit(pwr_ctx *c, Hdr *host_copy, unsigned host_seq)
+{
+    const int n = c->window;
+    hipLaunchKernelGGL(k_commit_scan, dim3(n, CS_G), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n);
+    hipLaunchKernelGGL(k_commit_apply, dim3(CA_G), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n);
+    hipLaunchKernelGGL(k_commit_finish, dim3(CA_G), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, n, c->d_rowids, host_copy, host_seq);
+    HIPC(hipGetLastError());
+    return PWR_OK;
+}
+
 static int enqueue_batch(pwr_ctx *c, Hdr *host_copy, unsigned host_seq)
 {
     int rc = enqueue_front(c);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, c->window, c->d_rowids, host_copy, host_seq);
-    HIPC(hipGetLastError());
-    return PWR_OK;
+    return enqueue_commit(c, host_copy, host_seq);
 }
 
 #define PWR_INFLIGHT 3             // batches enqueued beyond the last one whose outcome the host has seen
@@ -4377,11 +4496,10 @@ extern "C" int pwr_split_commit(pwr_ctx *c, const void *recv_dev, int *rows_left
     if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
     if (c->split_world > 1)
         hipLaunchKernelGGL(k_split_import, dim3(c->window), dim3(256), 0, c->stream, c->st, c->jb, c->window, static_cast<const unsigned char *>(recv_dev));
-    hipLaunchKernelGGL(k_commit_chain, dim3(1), dim3(COMMIT_NT), 0, c->stream, c->st, c->jb, c->window, c->d_rowids, static_cast<Hdr *>(nullptr), 0u);
-    HIPC(hipGetLastError());
-    Hdr h;
-    int rc = read_hdr(c, &h);                                                  // (waits for the stream)
+    int rc = enqueue_commit(c, static_cast<Hdr *>(nullptr), 0u);
     if (rc) return rc;
+    Hdr h;
+    if ((rc = read_hdr(c, &h))) return rc;                                     // (waits for the stream)
     c->seen_fallback = h.fallback; c->seen_need64 = h.need64;
     c->batch_ema = h.ema;
     stats_from_hdr(c, h);
@@ -4468,12 +4586,78 @@ extern "C" int pwr_export_rows(pwr_ctx *c, unsigned char *buf, size_t cap)
     if ((rc = dmalloc(c, &d, (size_t)chunk * W))) return rc;
     for (int r0 = 0; r0 < c->T; r0 += chunk) {
         const int nr = std::min(chunk, c->T - r0);
-        hipLaunchKernelGGL(k_export, dim3(nr), dim3(256), 0, c->stream, c->st, d, r0, nr, W);
+        hipLaunchKernelGGL(k_export, dim3(nr), dim3(256), 0, c->stream, c->st, d, r0, nr, W, 0);
         HIPC(hipMemcpyAsync(buf + (size_t)r0 * W, d, (size_t)nr * W, hipMemcpyDeviceToHost, c->stream));
         HIPC(hipStreamSynchronize(c->stream));
     }
     dfree(c, d);
     return PWR_OK;
+}
+
+// MMA_Auslesen (PW:1556-1598) without the caller waiting for it: the image of the FILE -- every row's characters and its
+// '\n' -- is made on the device in stream order (so the calls that follow may change the state at once) and copied to
+// page-locked host memory on a second stream; pwr_snapshot_wait blocks until it is there.  The 1.8 GB the drop-in rewrites
+// after every improving round (PW:1741) leave the critical path this way (pwr_host.c hands the image to a writer thread).
+extern "C" int pwr_snapshot_begin(pwr_ctx *c, pwr_snapshot **out)
+{
+    if (!c || !out) return PWR_ERR_ARG;
+    *out = nullptr;
+    if (c->snap_busy) return PWR_ERR_ARG;                                           // one at a time
+    int rc = ensure_device(c);
+    if (rc) return rc;
+    if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    Hdr h;
+    if ((rc = read_hdr(c, &h))) return rc;
+    const int W = h.W;
+    const size_t bytes = (size_t)c->T * (size_t)(W + 1);
+    if (bytes > c->snap_cap) {
+        if (c->snap_dev) { dfree(c, c->snap_dev); c->snap_dev = nullptr; }
+        if (c->snap_host) { (void)hipHostFree(c->snap_host); c->snap_host = nullptr; }
+        c->snap_cap = 0;
+        const size_t cap = bytes + bytes / 16 + 4096;                               // (the width moves a little from round to round)
+        if ((rc = dmalloc(c, &c->snap_dev, cap))) return rc;
+        void *hp = nullptr;
+        if (hipHostMalloc(&hp, cap, hipHostMallocDefault) != hipSuccess) { dfree(c, c->snap_dev); c->snap_dev = nullptr; return PWR_ERR_NOMEM; }
+        c->snap_host = (unsigned char *)hp;
+        c->snap_cap = cap;
+    }
+    if (!c->snap_stream) {
+        HIPC(hipStreamCreateWithFlags(&c->snap_stream, hipStreamNonBlocking));
+        HIPC(hipEventCreateWithFlags(&c->snap_taken, hipEventDisableTiming));
+        HIPC(hipEventCreateWithFlags(&c->snap_done, hipEventDisableTiming));
+    }
+    pwr_snapshot *sn = new (std::nothrow) pwr_snapshot{c, c->T, W, bytes};
+    if (!sn) return PWR_ERR_NOMEM;
+    if (bytes > 0) {
+        hipLaunchKernelGGL(k_export, dim3(c->T), dim3(256), 0, c->stream, c->st, c->snap_dev, 0, c->T, W, 1);
+        if (hipEventRecord(c->snap_taken, c->stream) != hipSuccess || hipStreamWaitEvent(c->snap_stream, c->snap_taken, 0) != hipSuccess ||
+            hipMemcpyAsync(c->snap_host, c->snap_dev, bytes, hipMemcpyDeviceToHost, c->snap_stream) != hipSuccess ||
+            hipEventRecord(c->snap_done, c->snap_stream) != hipSuccess) { delete sn; return PWR_ERR_DEVICE; }
+    }
+    c->snap_busy = true;
+    *out = sn;
+    return PWR_OK;
+}
+
+// (may be called from another thread than the one that drives the context)
+extern "C" int pwr_snapshot_wait(pwr_snapshot *sn, const unsigned char **image, size_t *bytes, int *rows, int *width)
+{
+    if (!sn || !sn->c) return PWR_ERR_ARG;
+    if (hipSetDevice(sn->c->device) != hipSuccess) return PWR_ERR_DEVICE;
+    if (sn->bytes > 0) HIPC(hipEventSynchronize(sn->c->snap_done));
+    if (image) *image = sn->c->snap_host;
+    if (bytes) *bytes = sn->bytes;
+    if (rows) *rows = sn->rows;
+    if (width) *width = sn->width;
+    return PWR_OK;
+}
+
+extern "C" void pwr_snapshot_free(pwr_snapshot *sn)
+{
+    if (!sn) return;
+    if (sn->c && sn->bytes > 0 && sn->c->snap_done) { (void)hipSetDevice(sn->c->device); (void)hipEventSynchronize(sn->c->snap_done); }
+    if (sn->c) sn->c->snap_busy = false;
+    delete sn;
 }
 
 extern "C" int pwr_trim_ends(pwr_ctx *c)
@@ -4507,6 +4691,8 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "seg_rows")) { if (c->on_device || value < 0 || value > 1000000) return PWR_ERR_ARG; c->seg_rows = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_align")) { if (c->on_device || (value != 16 && value != 32 && value != 64)) return PWR_ERR_ARG; c->seg_align = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
+    if (!strcmp(key, "seg_budget")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->seg_budget = (int)value; c->jb.seg_budget = (int)value; return PWR_OK; }
+    if (!strcmp(key, "seg_minrows")) { if (value < 16 || value > 100000) return PWR_ERR_ARG; c->seg_minrows = (int)value; c->jb.seg_minrows = (int)value; return PWR_OK; }
     if (!strcmp(key, "src_start")) { if (c->on_device || value < 0 || value > 1) return PWR_ERR_ARG; c->src_start = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_adapt")) { if (c->on_device || value < 0 || value > 1) return PWR_ERR_ARG; c->warm_adapt = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_down_pm")) { if (c->on_device || value < 1 || value > 1000) return PWR_ERR_ARG; c->warm_down_pm = (int)value; return PWR_OK; }
@@ -4531,6 +4717,8 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "onewg")) *value = c->one_wg;
     else if (!strcmp(key, "seg_rows")) *value = c->seg_rows;
     else if (!strcmp(key, "seg_max")) *value = c->seg_max;
+    else if (!strcmp(key, "seg_budget")) *value = c->seg_budget;
+    else if (!strcmp(key, "seg_minrows")) *value = c->seg_minrows;
     else if (!strcmp(key, "warm_pct")) *value = c->warm_pct;
     else if (!strcmp(key, "src_start")) *value = c->src_start;
     else if (!strcmp(key, "warm_adapt")) *value = c->warm_adapt;

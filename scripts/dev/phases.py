@@ -1,4 +1,5 @@
-"""dev (GPU box, libpwr_diag.so): where the time of a batch's tail goes -- phase timers of k_commit_chain and k_trace_par.
+"""dev (GPU box, libpwr_diag.so): where the time of a batch's tail goes -- phase timers of k_trace_blk (the commit is three
+launches since round 4: its phases are kernels, see scripts/kstats.sh).
 usage: phases.py [workload] [rows] [key=value ...]"""
 import ctypes, os, sys, time
 sys.path.insert(0, ".")
@@ -21,11 +22,7 @@ t0 = time.time(); g.realign_rows(100, n); dt = time.time() - t0
 lib.pwr_debug_phase_times(g._h, buf)
 st = g.stats()
 d = list(buf)
-nb = max(1, d[11]); nc = max(1, d[6]); nv = max(1, d[9])
 print(f"{n} rows in {dt:.3f} s, {st['batches']} batches ({1e3*dt/st['batches']:.3f} ms each), committed {st['rows_committed']}")
-print(f"commit kernel {d[10]/nb/100:.1f} us per launch ({nb} launches)")
-print(f"  validate: {d[0]/nv/100:.1f} us each x {nv}")
-print(f"  commit_job x {nc}: marks {d[1]/nc/100:.1f}  newcols {d[2]/nc/100:.1f}  updater {d[3]/nc/100:.1f}  pos/ends {d[4]/nc/100:.1f}  renumber {d[5]/nc/100:.1f} us; events/commit {d[7]/nc:.1f}, in place {d[8]/nc:.0%}")
 for nm, o in (("bottom chunk", 16), ("top chunk", 20)):
     k = max(1, d[o + 3])
     print(f"trace {nm}: phase0 {d[o]/k/100:.1f} us, waiting for the chunk above {d[o+1]/k/100:.1f} us, phase1 {d[o+2]/k/100:.1f} us  (job 0 of {k} launches)")

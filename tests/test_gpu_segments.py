@@ -21,7 +21,15 @@ def test_segmented_fill_row_by_row(name, bw, rounds, seg_rows, warm_pct, src_sta
     whether a warm-up starts from the column of the base before it alone (src_start 1, the default) or from the free start
     of PW:265 (0), and with a warm-up of 1.1 bandwidths that only the former can get away with (what it cannot is caught
     by the check and repeated)."""
-    _row_by_row(name, bw, rounds, oracle, seg_rows=seg_rows, seg_max=64, warm_pct=warm_pct, src_start=src_start)
+    _row_by_row(name, bw, rounds, oracle, seg_rows=seg_rows, seg_max=64, warm_pct=warm_pct, src_start=src_start, seg_budget=0)
+
+
+@pytest.mark.parametrize("budget,minrows,smax", [(200, 64, 256), (48, 16, 256), (400, 32, 256), (7, 64, 5)])
+@pytest.mark.parametrize("name,bw,rounds", SEG_CASES, ids=[c[0] for c in SEG_CASES])
+def test_budgeted_segments_row_by_row(name, bw, rounds, budget, minrows, smax, oracle):
+    """The same with the segments of a batch dealt from a budget by the rows' lengths (the default plan): finer than
+    seg_rows when there is room (down to 16 own rows), coarser when the budget is small, capped per job."""
+    _row_by_row(name, bw, rounds, oracle, seg_rows=128, seg_max=smax, warm_pct=200, seg_budget=budget, seg_minrows=minrows)
 
 
 def test_steered_warm_up_settles_and_changes_nothing(oracle):
@@ -86,15 +94,17 @@ def test_failed_segment_check_repeats_the_row_in_one_piece(oracle):
             g.close()
 
 
-def test_cells_computed_count_the_warm_up_rows(oracle):
-    """pwr_stats.cells_computed (the numerator of bench.py's roofline figure) against the plan restated here: segment s of
-    a row owns the rows [x_s, x_{s+1}), x_s = floor(L s / S) rounded down to 16, and warms up from the last multiple of 16
-    whose base lies at least warm_cols columns left of base x_s; every row of it costs min(B, W - anf) cells."""
+@pytest.mark.parametrize("budget,minrows", [(0, 64), (200, 64), (24, 32)])
+def test_cells_computed_count_the_warm_up_rows(budget, minrows, oracle):
+    """pwr_stats.cells_computed against the plan restated here: segment s of a row owns the rows [x_s, x_{s+1}),
+    x_s = floor(L s / S) rounded down to 16, and warms up from the last multiple of 16 whose base lies at least warm_cols
+    columns left of base x_s; every row of it costs min(B, W - anf) cells.  S: about seg_rows rows each (seg_budget 0), or the
+    batch's budget of segments dealt by length -- a batch of one row (window 1) has it to itself --, none shorter than seg_minrows."""
     from repeatresolver_amd.realigner import PWReAligner
     rows = split_rows(golden_input("toy_b_b1000"))
     bw, H, sr, smax, wp = 1000, 500, 128, 64, 150
     warm_cols = bw * wp // 100 + 2
-    g = PWReAligner(rows, bandwidth=bw, window=1, seg_rows=sr, seg_max=smax, warm_pct=wp, warm_adapt=0)   # (a fixed warm-up: the plan below)
+    g = PWReAligner(rows, bandwidth=bw, window=1, seg_rows=sr, seg_max=smax, warm_pct=wp, warm_adapt=0, seg_budget=budget, seg_minrows=minrows)   # (a fixed warm-up: the plan below)
     g.trim_ends()
     h = oracle.create(rows, bw)
     lib = oracle.lib
@@ -109,7 +119,7 @@ def test_cells_computed_count_the_warm_up_rows(oracle):
         W = lib.pwo_dbg_W_at_fill(h)
         way = np.ctypeslib.as_array(lib.pwo_dbg_way(h), (L,)).astype(np.int64)
         cells = np.minimum(bw, W - np.maximum(0, way - H))
-        S = max(1, min((L + sr // 2) // sr, smax, L // 128))
+        S = max(1, min((L + sr // 2) // sr, smax, L // 128)) if budget == 0 else max(1, min(budget, L // max(16, minrows), smax))
         xs = [(L * s // S) & ~15 for s in range(S)] + [L]
         for s in range(S):
             xb = 0
