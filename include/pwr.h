@@ -127,7 +127,7 @@ void pwr_snapshot_free(pwr_snapshot *snap);
  *               k_fill_v3 only; bandwidths above 1000 always use 9
  *   "onewg"     1 = the waves of a k_fill_v3 segment form ONE work-group and hand over through LDS (default 0: measured slower)
  *   "seg_rows", "seg_max", "warm_pct", "seg_align", "src_start"
- *               k_fill_v3 fills a DP as up to seg_max (<= 256) segments of about seg_rows (default 160) rows side
+ *               k_fill_v3 fills a DP as up to seg_max (<= 256, default 64) segments of about seg_rows (default 160) rows side
  *               by side, each warmed up while the band moves by warm_pct (default 190) percent of the bandwidth -- from the
  *               column of the base before its first row alone (src_start 1, default) or from the free start of PW:265 (0); with
  *               "warm_adapt" 1 (default, needs src_start) warm_pct is the upper bound of a length that follows the failures of the
@@ -137,10 +137,10 @@ void pwr_snapshot_free(pwr_snapshot *snap);
  *               one piece (pwr_stats.seg_fails).  seg_rows 0 = always in one piece; seg_align (16, 32, 64): the segments' first rows are
  *               multiples of it
  *   "seg_budget", "seg_minrows"
- *               segments the jobs of one batch may have TOGETHER (default 200: about one pipeline wave per SIMD of the chip), dealt
- *               to them by their rows' lengths -- a long row beside two short ones is cut finer than one of three long rows --,
- *               none with fewer own rows than seg_minrows (default 64), none with more segments than seg_max (default 256);
- *               seg_budget 0: about seg_rows rows per segment whatever the batch (the plan of round 3)
+ *               seg_budget > 0: the segments the jobs of one batch may have TOGETHER, dealt to them by their rows' lengths -- a long
+ *               row beside two short ones is cut finer than one of three long rows --, none with fewer own rows than seg_minrows
+ *               (default 64), none with more segments than seg_max; default 0 = about seg_rows rows per segment whatever the
+ *               batch (a budget of 160-320 was measured 7-20 % slower: every further segment brings its own warm-up)
  *   "ptrace"    traceback kernel: 2 = k_trace_blk (default: one wave per 64 rows, no hand-over chain), 1 = k_trace_par (64 chunks
  *               handing over top-down), 0 = k_trace_wp (one wave per job)
  *   "slack"     spare column capacity kept when the device arrays are (re)allocated

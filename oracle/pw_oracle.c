@@ -331,6 +331,48 @@ static int column_add(pwo_state *s, int y, int base, int k)
 }
 
 /* PW:1469-1531 Matrix_Filler + PW:1334-1454 Backtracker */
+/* dev aid (scripts/dev/start_vectors.py): the fill of row k against the state AS IT IS -- TheWay, the row taken out of the
+ * tallies, PW:1493-1513 -- without traceback or commit: the row is put back afterwards.  pwo_dbg_* then describe this fill. */
+int pwo_fill_only(pwo_state *s, int k)
+{
+    pwo_compact(s);
+    const int W = s->W, B = s->B;
+    s->Wfill = W;
+    int L = 0;
+    for (int i = 0; i < W; i++) {
+        int b = col_sym(s, s->order[i])[k];
+        if (b < 4) { if (L > MAX_SEQ_LEN) return -2; s->way[L] = i; s->seqb[L] = (unsigned char)b; L++; }
+    }
+    s->L = L;
+    if (L == 0) return 0;
+    for (int i = 0; i < W; i++) tally_sub(col_w(s, s->order[i]), col_sym(s, s->order[i])[k]);
+    for (int i = 0; i < W; i++) memcpy(s->dbg_tallies + (size_t)i * 6, col_w(s, s->order[i]), 6 * sizeof(uint64_t));
+    s->G[0] = 0;
+    for (int i = 0; i < W; i++) s->G[i + 1] = s->G[i] + S(s, i, 4);
+    if ((size_t)L * B > s->Mcap) {
+        free(s->M);
+        s->Mcap = (size_t)L * B;
+        s->M = malloc(s->Mcap * sizeof(uint64_t));
+        if (!s->M) { s->Mcap = 0; return -1; }
+    }
+    /* (the reads of Out() only see the row's own symbols through the tallies, so the symbols may stay) */
+    for (int x = 0; x < L; x++) {
+        int anf = anf_of(s, x);
+        int end = anf + B < W ? anf + B : W;
+        uint64_t *row = Mrow(s, x);
+        for (int y = anf; y < end; y++) {
+            uint64_t e = Out(s, x - 1, y - 1) + S(s, y, s->seqb[x]);
+            uint64_t left = (y - 1 < anf ? PWO_INF : row[y - 1 - anf]) + S(s, y, 4);
+            e = umin(e, left);
+            if (y > 0 && y < W - 1) e = umin(e, Out(s, x - 1, y) + umax(S(s, y, 5), S(s, y - 1, 5)));
+            row[y - anf] = e;
+        }
+    }
+    for (int i = 0; i < W; i++) tally_add(col_w(s, s->order[i]), col_sym(s, s->order[i])[k]);
+    return 0;
+}
+const uint64_t *pwo_dbg_Mrow(const pwo_state *s, int x) { return Mrow(s, x); }
+
 int pwo_realign_row(pwo_state *s, int k)
 {
     pwo_compact(s);                                       /* PW:1478 */

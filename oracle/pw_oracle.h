@@ -61,6 +61,10 @@ const unsigned char *pwo_dbg_newins(const pwo_state *s);
 int pwo_dbg_entry(const pwo_state *s);                   /* "wayin", PW:1352-1360 */
 /* band matrix value M[x][j] (j = y - anf(x)); UINT64_MAX/2-ish values are INF */
 uint64_t pwo_dbg_M(const pwo_state *s, int x, int j);
+/* dev aids (scripts/dev/start_vectors.py): the fill of row k against the state as it is, the state left unchanged; one
+ * whole DP row of the last fill (B values, band-relative) */
+int pwo_fill_only(pwo_state *s, int k);
+const uint64_t *pwo_dbg_Mrow(const pwo_state *s, int x);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,13 @@ def load():
     lib.pwr_split_stage.argtypes = [vp, vp]
     lib.pwr_split_commit.restype = ci
     lib.pwr_split_commit.argtypes = [vp, vp, ctypes.POINTER(ci)]
+    if hasattr(lib, "pwr_snapshot_begin"):
+        lib.pwr_snapshot_begin.restype = ci
+        lib.pwr_snapshot_begin.argtypes = [vp, ctypes.POINTER(vp)]
+        lib.pwr_snapshot_wait.restype = ci
+        lib.pwr_snapshot_wait.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        lib.pwr_snapshot_free.restype = None
+        lib.pwr_snapshot_free.argtypes = [vp]
     lib.pwr_debug_last_job.restype = ci
     lib.pwr_debug_last_job.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci),
                                        ctypes.POINTER(ci), ctypes.POINTER(ci), ci]

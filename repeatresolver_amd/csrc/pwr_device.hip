@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -167,7 +168,7 @@ struct JobBufs {
     int gstride;                   // rows per wave of a job's mailbox area
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
     unsigned long long *gtr;       // [njobs][trk]    k_trace_par / k_trace_blk: hand-over words of the chunks
-    int trk;                       // ... per job: max(TRK, Lmax / 64 + 1)
+    int trk;                       // ... per job: max(TRK, Lmax / TB_C + 1)
     unsigned trace_tag;            // 14-bit launch tag of those words
     long long *g64;                // [njobs][colcap] k_fill64: 64-bit prefix sums of S(.,4)
     int force64;                   // test hook: every job takes the 64-bit fill
@@ -601,12 +602,18 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_c(DState st, JobBufs jb)
         for (int w = 0; w < GATHER_NT / 64; ++w) tot += sh[w];
         __hip_atomic_store(&part[g].sum4, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&part[g].tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned carry = 0;
-        for (int q = 0; q < g; ++q) {
-            while (__hip_atomic_load(&part[q].tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(1);
-            carry += __hip_atomic_load(&part[q].sum4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid < 64) {
+        // the shares before this one, one lane each (one thread asking them in turn paid a round trip per share: the last
+        // share sixteen of them, on the critical path of every batch)
+        unsigned mine = 0;
+        if (tid < g) {
+            while (__hip_atomic_load(&part[tid].tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(1);
+            mine = __hip_atomic_load(&part[tid].sum4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_carry = carry;
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        if (tid == 0) s_carry = mine;
+    } else if (tid == 64) {
         uint32_t wl[6] = {0, 0, 0, 0, 0, 0};
         if (i0 > 0) tally_of(lo + i0 - 1, wl, nullptr);                              // coverage of the column left of the share
         s_covl = wl[5];
@@ -657,18 +664,22 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_c(DState st, JobBufs jb)
         __hip_atomic_store(&part[g].ucost, U, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&part[g].maxS, mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&part[g].lastcov, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // "second half done"
-        if (g == GATHER_G - 1) {
-            // 32-bit range.  The row's present placement is a path inside the band, so the optimum and every
-            // cell on an optimal path are <= U = its cost; larger values may saturate at PWR_INF without
-            // touching any test the traceback makes.  Offsets of at most (2B + slack) * maxS are added on top.
-            unsigned long long Ut = 0, cs = 0;
-            unsigned mxt = 0;
-            for (int q = 0; q < GATHER_G; ++q) {
-                while (__hip_atomic_load(&part[q].lastcov, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(1);
-                Ut += __hip_atomic_load(&part[q].ucost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                mxt = max(mxt, __hip_atomic_load(&part[q].maxS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                cs += part[q].cells;                                                 // (written by the launch before)
-            }
+    }
+    if (g == GATHER_G - 1 && tid < 64) {
+        // 32-bit range.  The row's present placement is a path inside the band, so the optimum and every
+        // cell on an optimal path are <= U = its cost; larger values may saturate at PWR_INF without
+        // touching any test the traceback makes.  Offsets of at most (2B + slack) * maxS are added on top.
+        // (all shares asked at once, one lane each)
+        unsigned long long Ut = 0, cs = 0;
+        unsigned mxt = 0;
+        if (tid < GATHER_G) {
+            while (__hip_atomic_load(&part[tid].lastcov, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(1);
+            Ut = __hip_atomic_load(&part[tid].ucost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mxt = __hip_atomic_load(&part[tid].maxS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            cs = part[tid].cells;                                                    // (written by the launch before)
+        }
+        for (int o = 32; o > 0; o >>= 1) { Ut += __shfl_xor(Ut, o); cs += __shfl_xor(cs, o); mxt = max(mxt, (unsigned)__shfl_xor((int)mxt, o)); }
+        if (tid == 0) {
             const unsigned long long bound = Ut + (unsigned long long)mxt * (unsigned long long)(2 * B + 4096);
             m->maxS = mxt; m->cells = cs;
             // the wave pipeline works with absolute prefix sums G: their total (= bases in the interval) must stay below 2^29
@@ -1996,7 +2007,6 @@ __global__ __launch_bounds__(256) void k_seg_check(DState st, JobBufs jb)
     for (int j = tid; j < Bx; j += 256) {
         const int idx = (a + j - lo) % RS;
         const unsigned vw = cw[idx], vt = ct[idx];
-        cw[idx] = 0xffffffffu; ct[idx] = 0xffffffffu;
         if (vw == 0xffffffffu || vt == 0xffffffffu) bad = 1;                       // a band cell nobody stored
         else if ((vw >= PWR_INF) != (vt >= PWR_INF)) bad = 1;
         else if (vw < PWR_INF) { const int d = (int)(vw - vt); dmin = min(dmin, d); dmax = max(dmax, d); }
@@ -2005,6 +2015,9 @@ __global__ __launch_bounds__(256) void k_seg_check(DState st, JobBufs jb)
     if ((tid & 63) == 0) { s_min[tid >> 6] = dmin; s_max[tid >> 6] = dmax; }
     if (bad) s_bad = 1;
     __syncthreads();
+    // the entries are consumed -- the WHOLE strip, not only the band cells read: a later fill that skips a store must meet
+    // "not written", never a finite value left over from an earlier launch
+    for (int j = tid; j < RS; j += 256) { cw[j] = 0xffffffffu; ct[j] = 0xffffffffu; }
     if (tid == 0) {
         const int lo_ = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3])), hi_ = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
         if (s_bad || (lo_ != INT_MAX && lo_ != hi_)) m->segfail = 1;
@@ -2590,7 +2603,7 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
 }
 
 // ---------------------------------------------------------------------------------------------
-// trace, one wave per 64-row block ("chunk"), hand-over without a chain.  As in k_trace_par every chunk but the top one
+// trace, one wave per TB_C-row block ("chunk"), hand-over without a chain.  As in k_trace_par every chunk but the top one
 // first traces its rows from a GUESSED arrival column (just left of where the row above sits now) and records, per row,
 // the arrival column and the placement; it then posts a word {arrival column it started from, exit column, 'up' moves}.
 // What k_trace_par resolves top-down, one chunk after the other (a chain of L / 192 hand-overs, a third of its time), every
@@ -2608,6 +2621,8 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
 // (exit field all ones: the pass broke off inside the chunk)
 // ---------------------------------------------------------------------------------------------
 #define TB_W 4                                          // chunks per work-group
+#define TB_C 32                                         // rows per chunk (one lane per row; a row of the trace costs ~290 ns of dependent
+                                                        // instructions, so a chunk half as long is traced in half the time: 64 -> 32 rows, 30 -> 20 us)
 #define TB_BROKE 0x1fffffu
 #define TB_WORD(TAG, FLAG, CNT, ARR, EXF) (((unsigned long long)((TAG) & 0x3fffu) << 50) | ((unsigned long long)(FLAG) << 48) | ((unsigned long long)((CNT) & 0x7f) << 41) | \
                                            ((unsigned long long)(((ARR) + 1) & 0xfffff) << 21) | (unsigned long long)((EXF) & 0x1fffffu))
@@ -2618,7 +2633,7 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
     if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows) || NOT_MINE(jb, job)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
-    const int nch = (L + 63) >> 6;
+    const int nch = (L + TB_C - 1) / TB_C;
     // the top chunks first: they are the ones everybody else waits for
     const int c = nch - 1 - UNI((int)blockIdx.y * TB_W + (tid >> 6));
     if (c < 0) return;
@@ -2630,7 +2645,7 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
     const unsigned *lastM = jb.lastM + (size_t)job * jb.NC;
     int *newcol = jb.newcol + (size_t)job * jb.Lmax;
     int *yin = jb.aux + (size_t)job * jb.Lmax;             // arrival column per row (aux is rewritten by the commit later)
-    const int x_lo = c << 6, x_top = min(L, x_lo + 64) - 1;
+    const int x_lo = c * TB_C, x_top = min(L, x_lo + TB_C) - 1;
     const bool top = c == nch - 1;
     const int wcur = way[min(x_lo + lane, L - 1)];         // Way[] of the chunk's rows, one per lane
     int ncreg = 0, yireg = 0;                              // the chunk's record, one row per lane
@@ -2653,8 +2668,8 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
             // ---- the common case, straight: rows of the current 16-row group whose step lies in the 64-cell part of the window
             //      that holds the current column
             while ((x >> 4) == gcur && x >= x_lo) {
-                if (check_merge && x >= xrec_lo && __builtin_amdgcn_readlane(yireg, x & 63) == y) { merged = true; break; }
-                const int af = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+                if (check_merge && x >= xrec_lo && __builtin_amdgcn_readlane(yireg, x & (TB_C - 1)) == y) { merged = true; break; }
+                const int af = max(0, __builtin_amdgcn_readlane(wcur, x & (TB_C - 1)) - H);
                 const int ycf = min(y, af + min(B, W - af) - 1);
                 if (y < af || ycf < yb || ycf > yb + 255) break;
                 const int q0 = (ycf - yb) >> 6, shf = 15 - (x & 15);
@@ -2666,17 +2681,17 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
                 const int yy = yb + 64 * q0 + t;
                 const int cb = (int)((__ballot((wq >> (16 + shf)) & 1u) >> t) & 1ull);
                 const int nv = (yy << 1) | (cb ^ 1);                               // PW:1394 (c) / PW:1404 (d)
-                if (x >= xrec_lo) cnt -= __builtin_amdgcn_readlane(ncreg, x & 63) & 1;
+                if (x >= xrec_lo) cnt -= __builtin_amdgcn_readlane(ncreg, x & (TB_C - 1)) & 1;
                 cnt += nv & 1;
-                ncreg = (lane == (x & 63)) ? nv : ncreg;
-                yireg = (lane == (x & 63)) ? y : yireg;
+                ncreg = (lane == (x & (TB_C - 1))) ? nv : ncreg;
+                yireg = (lane == (x & (TB_C - 1))) ? y : yireg;
                 y = yy - cb;                                                       // diag: column to the left, up: stay
                 --x;
                 if (x >= 0 && y < 0) { e = 3; break; }
             }
             if (merged || e || x < x_lo) break;
-            if (check_merge && x >= xrec_lo && __builtin_amdgcn_readlane(yireg, x & 63) == y) { merged = true; break; }
-            const int a = max(0, __builtin_amdgcn_readlane(wcur, x & 63) - H);
+            if (check_merge && x >= xrec_lo && __builtin_amdgcn_readlane(yireg, x & (TB_C - 1)) == y) { merged = true; break; }
+            const int a = max(0, __builtin_amdgcn_readlane(wcur, x & (TB_C - 1)) - H);
             const int Bx = min(B, W - a);
             if (y < a) { e = 1; break; }
             int yc = min(y, a + Bx - 1);                     // past the band: implicit left moves
@@ -2736,10 +2751,10 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
             if (e) break;
             const int yy = found;
             const int nv = cbit ? (yy << 1) : ((yy << 1) | 1);                       // PW:1394 (c) / PW:1404 (d)
-            if (x >= xrec_lo) cnt -= __builtin_amdgcn_readlane(ncreg, x & 63) & 1;   // replaces a recorded step
+            if (x >= xrec_lo) cnt -= __builtin_amdgcn_readlane(ncreg, x & (TB_C - 1)) & 1;   // replaces a recorded step
             cnt += nv & 1;
-            ncreg = (lane == (x & 63)) ? nv : ncreg;
-            yireg = (lane == (x & 63)) ? y : yireg;
+            ncreg = (lane == (x & (TB_C - 1))) ? nv : ncreg;
+            yireg = (lane == (x & (TB_C - 1))) ? y : yireg;
             y = cbit ? yy - 1 : yy;
             --x;
             if (x >= 0 && y < 0) { e = 3; break; }
@@ -2866,9 +2881,9 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
         if (!err && broke) err = 6;                               // the true trace breaks off in this chunk
         if (!err) { TB_POST(2, arr) }
     }
-    if (x_lo + lane < L) { newcol[x_lo + lane] = ncreg; yin[x_lo + lane] = yireg; }
+    if (lane < TB_C && x_lo + lane < L) { newcol[x_lo + lane] = ncreg; yin[x_lo + lane] = yireg; }
     // did any base of the chunk move (or open a column)?  If none of the row's does, its commit has nothing to do.
-    if (__ballot(x_lo + lane < L && ncreg != (wcur << 1)) != 0ull && lane == 0) __hip_atomic_store(&m->changed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__ballot(lane < TB_C && x_lo + lane < L && ncreg != (wcur << 1)) != 0ull && lane == 0) __hip_atomic_store(&m->changed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (top || err) {
         if (lane == 0)
             __hip_atomic_store(&hand[c], TB_WORD(ttag, err ? 3 : 2, cnt, 0, (unsigned)(yexit + 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2956,8 +2971,8 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_scan(DState st, JobBufs jb
     if (!m->active || m->L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows)) return;   // cannot commit in this batch
     const int k = m->k, L = m->L;
     if (!m->changed && st.nbrk[k] == 0) return;           // the traceback left every base where it was (k_trace_blk): nothing changes
-    const int nch = (L + 63) >> 6;
-    const bool chunked = jb.trace_blk != 0 && nch <= COMMIT_NT;     // k_trace_blk counted the 'up' moves of every 64 rows
+    const int nch = (L + TB_C - 1) / TB_C;
+    const bool chunked = jb.trace_blk != 0 && nch <= COMMIT_NT;     // k_trace_blk counted the 'up' moves of every TB_C rows
     const int G = (chunked && L >= 64 * CS_G) ? CS_G : 1;
     if (g >= G) return;
     CommitJob *cj = &jb.cjob[job];
@@ -3026,8 +3041,10 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_scan(DState st, JobBufs jb
         const unsigned ins = (x < x1 && (c & 1)) ? 1u : 0u;
         int idx;
         if (chunked) {
+            // (the bases before it in its chunk: x0 is a multiple of 64, so a wave holds whole chunks)
             const unsigned long long bal = __ballot(ins != 0u);
-            idx = s_cpre[min(x, L - 1) >> 6] + __builtin_popcountll(bal & ((1ull << (tid & 63)) - 1ull));
+            const int ln = tid & 63, l0 = ln & ~(TB_C - 1);
+            idx = s_cpre[min(x, L - 1) / TB_C] + __builtin_popcountll(bal & ((1ull << ln) - 1ull) & ~((1ull << l0) - 1ull));
         } else {
             unsigned tot;
             const unsigned incl = block_incl_add<COMMIT_NT>(ins, sh, tot);
@@ -3057,26 +3074,52 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_scan(DState st, JobBufs jb
     {
         const unsigned long long *mo8 = reinterpret_cast<const unsigned long long *>(mark), *mn8 = reinterpret_cast<const unsigned long long *>(mark2);
         const int ui0 = max(way0, ny0), ui1 = min(wayL, nyL);                      // columns inside both extents
-        for (int u = ((Y0 - lo) >> 3) + tid; u <= ((Y1 - 1 - lo) >> 3); u += COMMIT_NT) {
-            const int yb8 = lo + 8 * u;
-            const unsigned long long wo = mo8[u], wn = mn8[u];
-            if (yb8 >= ui0 && yb8 + 7 <= ui1 && wo == wn) continue;
+        __shared__ int s_base;
+        const int u_last = (Y1 - 1 - lo) >> 3;
+        for (int ub = (Y0 - lo) >> 3; ub <= u_last; ub += COMMIT_NT) {
+            const int u = ub + tid;
+            int ent[8];
+            int cnt = 0;
+            if (u <= u_last) {
+                const int yb8 = lo + 8 * u;
+                const unsigned long long wo = mo8[u], wn = mn8[u];
+                if (!(yb8 >= ui0 && yb8 + 7 <= ui1 && wo == wn)) {
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const int y = yb8 + b;
-                if (y < Y0 || y >= Y1 || y < u0 || y > u1) continue;               // (the unit's other bytes are a neighbour share's)
-                const int vo = (int)((wo >> (8 * b)) & 0xffull), vn = (int)((wn >> (8 * b)) & 0xffull);
-                const int so = (y < way0 || y > wayL) ? 5 : (vo == 7 ? 5 : (vo ? vo - 1 : 4));     // row_symbol()
-                const int sn = (y < ny0 || y > nyL) ? 5 : (vn == 7 ? 5 : (vn ? vn - 1 : 4));
-                if (so == sn) continue;
-                list[atomicAdd(&cj->nchg, 1)] = y | (so << 24) | (sn << 28);
-                touch(y, 0);
-                if (so < 4 && sn >= 4 && st.tally[order[y]].w[4] == 1u) {          // the row's base was the column's last: W_Con will drop it
-                    event(2 * y, -1);
-                    atomicAdd(&cj->ndel, 1);
-                    touch(y, -1);
+                    for (int b = 0; b < 8; ++b) {
+                        const int y = yb8 + b;
+                        const int vo = (int)((wo >> (8 * b)) & 0xffull), vn = (int)((wn >> (8 * b)) & 0xffull);
+                        const int so = (y < way0 || y > wayL) ? 5 : (vo == 7 ? 5 : (vo ? vo - 1 : 4));     // row_symbol()
+                        const int sn = (y < ny0 || y > nyL) ? 5 : (vn == 7 ? 5 : (vn ? vn - 1 : 4));
+                        // (the unit's bytes outside [Y0, Y1) are a neighbour share's)
+                        const bool chg = y >= Y0 && y < Y1 && y >= u0 && y <= u1 && so != sn;
+                        ent[b] = chg ? (y | (so << 24) | (sn << 28)) : -1;
+                        cnt += chg ? 1 : 0;
+                    }
                 }
             }
+            // (one reservation in the job's list per work-group and pass: an atomic per changed column -- thousands per commit
+            // of the first round, all on one word -- was what the kernel waited for)
+            unsigned tot;
+            const unsigned incl = block_incl_add<COMMIT_NT>((unsigned)cnt, sh, tot);
+            if (tid == 0 && tot) s_base = atomicAdd(&cj->nchg, (int)tot);
+            __syncthreads();
+            if (cnt) {
+                int w_ = s_base + (int)(incl - (unsigned)cnt);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    if (ent[b] < 0) continue;
+                    const int e_ = ent[b];
+                    const int y = e_ & 0xffffff, so = (e_ >> 24) & 15, sn = (e_ >> 28) & 15;
+                    list[w_++] = e_;
+                    touch(y, 0);
+                    if (so < 4 && sn >= 4 && st.tally[order[y]].w[4] == 1u) {      // the row's base was the column's last: W_Con will drop it
+                        event(2 * y, -1);
+                        atomicAdd(&cj->ndel, 1);
+                        touch(y, -1);
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -3088,7 +3131,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_scan(DState st, JobBufs jb
 // for the columns the commits before have opened or emptied inside the stale row's interval, which its NEXT gather will see
 // shifted by as many).  The DP depends on absolute positions only through the clamps at the MSA's edges, which disjoint
 // intervals rule out (commutation probe), so realigning j after i gives the state the reference reaches with j before i.
-__device__ void commit_decide(const DState &st, const JobBufs &jb, int njobs, BatchPlan *p)
+__device__ void commit_decide(const DState &st, const JobBufs &jb, int njobs, BatchPlan *p, const JobMeta *metas, const CommitJob *cjobs, const int *pair_cf, const int *pair_left)
 {
     const Hdr *h = st.hdr;
     p->idle = (h->status != 0 || h->need_grow) ? 1 : 0;
@@ -3104,7 +3147,7 @@ __device__ void commit_decide(const DState &st, const JobBufs &jb, int njobs, Ba
     int skipped[MAXJ];
     bool stopped = false;
     for (int j = 0; j < njobs && j < MAXJ; ++j) {
-        const JobMeta *m = &jb.meta[j];
+        const JobMeta *m = &metas[j];
         if (!m->active) break;                                                    // the batch ends here
         if (m->L > 0) {
             p->live_all += 1;
@@ -3120,14 +3163,14 @@ __device__ void commit_decide(const DState &st, const JobBufs &jb, int njobs, Ba
             int d = 0, r = 0;                                                     // columns the jobs committed before open (net) left / right of this job's interval
             for (int t = 0; t < p->ncommit && good; ++t) {
                 const int i = p->cjobs[t];
-                const CommitJob *ci = &jb.cjob[i];
+                const CommitJob *ci = &cjobs[i];
                 if (!ci->scanned) continue;                                       // (committed without a change)
-                if (jb.pair_cf[(size_t)i * njobs + j]) { good = false; why = 3; break; }
-                const int neti = jb.meta[i].nnew - ci->ndel;
+                if (pair_cf[(size_t)i * njobs + j]) { good = false; why = 3; break; }
+                const int neti = metas[i].nnew - ci->ndel;
                 int left;
                 if (ci->u1 < m->lo - 1) left = neti;                              // all its events lie left of the interval's margin
                 else if (m->hi + 1 < ci->u0 - 1) left = 0;                        // ... right of it
-                else left = jb.pair_left[(size_t)i * njobs + j];
+                else left = pair_left[(size_t)i * njobs + j];
                 d += left; r += neti - left;
             }
             if (good && (d != 0 || r != 0)) {
@@ -3139,7 +3182,7 @@ __device__ void commit_decide(const DState &st, const JobBufs &jb, int njobs, Ba
                 if (good && !(far_old && far_new) && r != 0) { good = false; why = 2; }                   // right clamp PW:1497/1505
             }
             for (int t = 0; t < nskip && good; ++t) {
-                const JobMeta *ms = &jb.meta[skipped[t]];
+                const JobMeta *ms = &metas[skipped[t]];
                 if (!(m->hi + 2 + evabs < ms->lo || ms->hi + 2 + evabs < m->lo)) good = false;
             }
             if (!good) {
@@ -3152,7 +3195,7 @@ __device__ void commit_decide(const DState &st, const JobBufs &jb, int njobs, Ba
             p->verdict[j] = V_COMMIT;
             p->cjobs[p->ncommit] = j; p->slotbase[p->ncommit] = p->nnew;
             p->ncommit += 1;
-            const CommitJob *cj = &jb.cjob[j];
+            const CommitJob *cj = &cjobs[j];
             if (cj->scanned) {
                 p->nnew += m->nnew; p->ndel += cj->ndel; p->nev += cj->nev;
                 net += m->nnew - cj->ndel; evabs += cj->nev;
@@ -3211,8 +3254,20 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_apply(DState st, JobBufs j
 {
     __shared__ BatchPlan sp;
     __shared__ CommitEv ev;
+    __shared__ JobMeta s_meta[MAXJ];
+    __shared__ CommitJob s_cj[MAXJ];
+    __shared__ int s_pcf[16 * 16], s_pl[16 * 16];
     const int tid = threadIdx.x;
-    if (tid == 0) commit_decide(st, jb, njobs, &sp);
+    {
+        // what the decision reads, fetched by all threads at once (one thread walking it through dependent loads took as long
+        // as the rest of the kernel)
+        const int nj = min(njobs, MAXJ);
+        for (int i = tid; i < nj * (int)(sizeof(JobMeta) / 4); i += COMMIT_NT) reinterpret_cast<int *>(s_meta)[i] = reinterpret_cast<const int *>(jb.meta)[i];
+        for (int i = tid; i < nj * (int)(sizeof(CommitJob) / 4); i += COMMIT_NT) reinterpret_cast<int *>(s_cj)[i] = reinterpret_cast<const int *>(jb.cjob)[i];
+        if (njobs <= 16) for (int i = tid; i < njobs * njobs; i += COMMIT_NT) { s_pcf[i] = jb.pair_cf[i]; s_pl[i] = jb.pair_left[i]; }
+        __syncthreads();
+        if (tid == 0) commit_decide(st, jb, njobs, &sp, s_meta, s_cj, njobs <= 16 ? s_pcf : jb.pair_cf, njobs <= 16 ? s_pl : jb.pair_left);
+    }
     __syncthreads();
     if (blockIdx.x == 0)
         for (int i = tid; i < (int)(sizeof(BatchPlan) / 4); i += COMMIT_NT) reinterpret_cast<int *>(jb.plan)[i] = reinterpret_cast<const int *>(&sp)[i];
@@ -3305,8 +3360,10 @@ __device__ __forceinline__ void publish_header(const Hdr *h, Hdr *host_copy, uns
 {
     if (!host_copy) return;
     constexpr int NWORDS = (int)(sizeof(Hdr) / 4), SEQW = (int)(offsetof(Hdr, seq) / 4);
-    if ((int)threadIdx.x < NWORDS && (int)threadIdx.x != SEQW) reinterpret_cast<volatile int *>(host_copy)[threadIdx.x] = reinterpret_cast<const int *>(h)[threadIdx.x];
-    __threadfence_system();
+    if ((int)threadIdx.x < NWORDS && (int)threadIdx.x != SEQW) {
+        reinterpret_cast<volatile int *>(host_copy)[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const int *>(h) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();                                                    // (by the waves that wrote)
+    }
     __syncthreads();
     if (threadIdx.x == 0) { *reinterpret_cast<volatile unsigned *>(&host_copy->seq) = seq; __threadfence_system(); }
 }
@@ -3424,11 +3481,18 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
         if (tid == 0) jb.sev->cum = Wnew - W;                                      // (for the work-group that writes the header)
     }
     // ---- the last work-group to get here writes the header
+    // (every wave's stores are drained and the work-group's barrier passed before ONE lane releases them and takes a ticket;
+    // the last arriver's lane acquires before anybody of its work-group reads on)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) { __threadfence(); s_last = atomicAdd(jb.ticket, 1u) == gridDim.x - 1 ? 1 : 0; }
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = __hip_atomic_fetch_add(jb.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+        if (s_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     if (tid == 0) {
         *jb.ticket = 0u;
         h->ncommitted = 0; h->stop = 0;
@@ -3499,7 +3563,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
             }
         }
     }
-    __threadfence();
+    if (tid == 0) __threadfence();
     __syncthreads();
     publish_header(h, host_copy, host_seq);
 }
@@ -3529,7 +3593,7 @@ __global__ __launch_bounds__(256) void k_split_export(JobBufs jb, int njobs, uns
     for (int x = tid; x < m->L; x += 256) nc[x] = src[x];
     unsigned long long *gt = reinterpret_cast<unsigned long long *>(slot + sizeof(JobMeta) + (size_t)jb.Lmax * 4);
     const unsigned long long *gs = jb.gtr + (size_t)job * jb.trk;
-    const int nch = min(jb.trk, (m->L + 63) >> 6);
+    const int nch = min(jb.trk, (m->L + TB_C - 1) / TB_C);
     for (int i = tid; i < nch; i += 256) gt[i] = gs[i];
 }
 
@@ -3560,7 +3624,7 @@ __global__ __launch_bounds__(256) void k_split_import(DState st, JobBufs jb, int
     for (int x = tid; x < L; x += 256) dst[x] = nc[x];
     const unsigned long long *gt = reinterpret_cast<const unsigned long long *>(slot + sizeof(JobMeta) + (size_t)jb.Lmax * 4);
     unsigned long long *gd = jb.gtr + (size_t)job * jb.trk;
-    const int nch = min(jb.trk, (L + 63) >> 6);
+    const int nch = min(jb.trk, (L + TB_C - 1) / TB_C);
     for (int i = tid; i < nch; i += 256) gd[i] = gt[i];
 }
 
@@ -3666,8 +3730,8 @@ struct pwr_ctx {
     int one_wg = 0;                       // k_fill_v3: the waves of a segment as one work-group (hand-over through LDS); 0: one work-group per wave
     int seg_rows = 160;                   // k_fill_v3: a DP is filled in segments of about this many rows, side by side (0: in one piece)
     int seg_align = 16;                   // ... whose own parts start at multiples of this many rows (16 / 32 / 64)
-    int seg_max = SEG_MAX;                // ... at most this many per DP (<= SEG_MAX)
-    int seg_budget = 200;                 // ... and this many for all the jobs of a batch together, dealt by length (0: seg_rows rows each, whatever that gives)
+    int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
+    int seg_budget = 0;                   // > 0: this many for all the jobs of a batch together, dealt by length (measured slower; 0: seg_rows rows each)
     int seg_minrows = 64;                 // ... none with fewer own rows than this
     int split_rank = 0, split_world = 1;  // pwr_split_*: this context is replica split_rank of split_world (one per GPU)
     int split_k0 = 0, split_kend = 0;     // ... rows of the slab in progress
@@ -3912,7 +3976,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
             hipStreamSynchronize(c->stream) != hipSuccess) return PWR_ERR_DEVICE;
         c->fill_epoch = 0;
     }
-    jb.trk = std::max(TRK, jb.Lmax / 64 + 1);
+    jb.trk = std::max(TRK, jb.Lmax / TB_C + 1);
     if ((rc = dmalloc(c, &jb.gtr, (size_t)njobs * jb.trk))) return rc;
     if ((rc = dmalloc(c, &jb.diag, (size_t)njobs * 32 * 4096))) return rc;
     if (hipMemsetAsync(jb.diag, 0, (size_t)njobs * 32 * 4096 * 8, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
@@ -4301,7 +4365,7 @@ static int enqueue_front(pwr_ctx *c)
         if (++c->trace_epoch >= (1u << 14)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * c->jb.trk * 8, c->stream)); c->trace_epoch = 1; }
         c->jb.trace_tag = c->trace_epoch;
         c->jb.trace_blk = (c->par_trace == 2 && c->st.colcap < TB_MAXCOL) ? 1 : 0;
-        if (c->jb.trace_blk) hipLaunchKernelGGL(k_trace_blk, dim3(n, (c->jb.Lmax / 64 + TB_W) / TB_W), dim3(TB_W * 64), 0, c->stream, c->st, c->jb);
+        if (c->jb.trace_blk) hipLaunchKernelGGL(k_trace_blk, dim3(n, (c->jb.Lmax / TB_C + TB_W) / TB_W), dim3(TB_W * 64), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
     }
     else { c->jb.trace_blk = 0; hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb); }
@@ -4328,6 +4392,7 @@ static int enqueue_batch(pwr_ctx *c, Hdr *host_copy, unsigned host_seq)
 }
 
 #define PWR_INFLIGHT 3             // batches enqueued beyond the last one whose outcome the host has seen
+#define PWR_POLL_LIMIT_S 120       // how long the host waits for the header of ONE batch before it gives the context up
 
 // Start a slab: rows [k0, k0 + n), first batch sized like the host did before (the running mean carries over).  (After a
 // regrow a slab goes on where it stood instead: the device's row pointer and its mask of rows already committed ahead of
@@ -4383,12 +4448,25 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
             // wait for that batch's header: poll the sequence number (pinned memory), look at the stream now and then in case
             // it has died
             volatile unsigned *sq = &ring[slot].seq;
+            std::chrono::steady_clock::time_point t_wait{};
             for (unsigned long long spin = 1; *sq != seqs[slot]; ++spin) {
-                if ((spin & 0xfffffull) == 0 && hipStreamQuery(c->stream) == hipSuccess && *sq != seqs[slot]) {
-                    // the stream is idle and the header never came: a launch failed
-                    hipError_t e = hipGetLastError();
-                    fprintf(stderr, "pwr: a batch ended without its header (%s)\n", hipGetErrorString(e));
-                    return PWR_ERR_DEVICE;
+                if ((spin & 0xfffffull) == 0) {
+                    if (hipStreamQuery(c->stream) == hipSuccess && *sq != seqs[slot]) {
+                        // the stream is idle and the header never came: a launch failed
+                        hipError_t e = hipGetLastError();
+                        fprintf(stderr, "pwr: a batch ended without its header (%s)\n", hipGetErrorString(e));
+                        return PWR_ERR_DEVICE;
+                    }
+                    // a batch takes a fraction of a millisecond, a wave that waits in vain for its neighbour gives up after 0.2 s
+                    // (V3_TIMEOUT_TICKS) and the stand-in kernel takes milliseconds: a header that has not come after PWR_POLL_LIMIT_S
+                    // seconds never will (a kernel that does not end).  Say which one, and return instead of spinning for ever.
+                    const auto now = std::chrono::steady_clock::now();
+                    if (t_wait == std::chrono::steady_clock::time_point{}) t_wait = now;
+                    else if (std::chrono::duration<double>(now - t_wait).count() > PWR_POLL_LIMIT_S) {
+                        fprintf(stderr, "pwr: no header from batch %lld of the slab (sequence %u) after %d s: a kernel of it does not end\n", looked, seqs[slot], PWR_POLL_LIMIT_S);
+                        return PWR_ERR_STALL;
+                    }
+                    std::this_thread::yield();
                 }
 #if !defined(__HIP_DEVICE_COMPILE__)
                 __builtin_ia32_pause();

@@ -121,6 +121,20 @@ class PWReAligner:
         raw = buf.raw[:t * w]
         return [raw[i * w:(i + 1) * w] for i in range(t)]
 
+    def snapshot_begin(self):                # MMA_Auslesen's file image, taken in stream order and copied out on a stream of its own
+        sn = ctypes.c_void_p()
+        _check(self._lib.pwr_snapshot_begin(self._h, ctypes.byref(sn)), "pwr_snapshot_begin")
+        return sn
+
+    def snapshot_wait(self, sn) -> bytes:    # the image (rows of `width` characters, each followed by a newline); frees the snapshot
+        img, n, t, w = ctypes.c_void_p(), ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int()
+        try:
+            _check(self._lib.pwr_snapshot_wait(sn, ctypes.byref(img), ctypes.byref(n), ctypes.byref(t), ctypes.byref(w)), "pwr_snapshot_wait")
+            assert n.value == t.value * (w.value + 1)
+            return ctypes.string_at(img.value, n.value) if n.value else b""
+        finally:
+            self._lib.pwr_snapshot_free(sn)
+
     def stats(self):
         s = _lib.PwrStats()
         _check(self._lib.pwr_get_stats(self._h, ctypes.byref(s)), "pwr_get_stats")

@@ -155,6 +155,18 @@ def test_argument_and_input_errors(tmp_path):
     assert read(b"acgt\nacgt") == -4                      # last line without newline, PW:134
     assert read(b"acgt\nacg\n") == -4                     # unequal lengths: refused
     assert read(b"") == -4
+    # the regular case goes through one read and row-parallel checks (1.8 GB at benchmark scale): same bytes, and anything
+    # irregular -- here a file whose size fits but whose 501st line is cut in two -- still gets the line-by-line refusal
+    big = b"".join(bytes(b"acgt-"[(i * 7 + j) % 5] for j in range(37)) + b"\n" for i in range(1000))
+    assert read(big) == 0 and (T.value, W.value) == (1000, 37)
+    assert bytes(txt[:1000 * 37]) == big.replace(b"\n", b"")
+    bad = bytearray(big)
+    bad[38 * 500 + 10] = ord("\n")
+    bad[38 * 500 + 37] = ord("a")
+    assert read(bytes(bad)) == -4 and b"line 501 has 10 characters" in err.value
+    nul = bytearray(big)
+    nul[38 * 3 + 5] = 0
+    assert read(bytes(nul)) == -4
     assert lib.pwr_read_msa_file(str(tmp_path / "nope").encode(), ctypes.byref(T), ctypes.byref(W),
                                  ctypes.byref(txt), err, 256) == -4
     assert err.value == b"MA is missing."                  # PW:121

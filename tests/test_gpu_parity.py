@@ -412,3 +412,34 @@ def test_medium_properties_and_kernel_cross_check():
             ref = (s1, out, st["cells_reference"])
         else:
             assert (s1, out, st["cells_reference"]) == ref
+
+
+def test_snapshot_is_the_file_the_reference_would_write(oracle):
+    """pwr_snapshot_*: the image of MMA_Auslesen's file (PW:1556-1598) taken in stream order -- the realignments that follow
+    do not change it --, one at a time; the drop-in's writer thread hands exactly these bytes to the file (the CLI fixtures
+    compare the files themselves)."""
+    from repeatresolver_amd.realigner import PWReAligner, PwrError
+    rows = split_rows(golden_input("toy_b_b1000"))
+    g = PWReAligner(rows, bandwidth=1000)
+    g.trim_ends()
+    for rnd in range(2):
+        g.realign_round()
+        want = b"".join(r + b"\n" for r in g.export_rows())
+        sn = g.snapshot_begin()
+        with pytest.raises(PwrError) as e:
+            g.snapshot_begin()                              # one at a time
+        assert e.value.code == -1
+        g.realign_rows(0, min(8, len(rows)))                # the state moves on at once; the image is the one taken
+        assert g.snapshot_wait(sn) == want
+    # ... and against the oracle after a further round: the same bytes the reference's file holds
+    h = oracle.create(rows, 1000)
+    oracle.lib.pwo_trim(h)
+    g2 = PWReAligner(rows, bandwidth=1000)
+    g2.trim_ends()
+    g2.realign_round()
+    oracle.lib.pwo_realign_round(h)
+    oracle.lib.pwo_compact(h)
+    assert g2.snapshot_wait(g2.snapshot_begin()) == b"".join(r + b"\n" for r in oracle.export(h))
+    oracle.lib.pwo_destroy(h)
+    g.close()
+    g2.close()
