@@ -73,8 +73,19 @@ def pipeline(work, threads):
     json.dump(fx, open(fx_path, "w"), indent=1)
 
     out = os.path.join(work, "p_out.msa")
-    recs = []
-    gf.watch_reference(msa, out, T, 1, recs.append, "[pw_ref]")
+    recs, said = [], []
+    plain_log = gf.log
+
+    def keep(*a):                                          # the reference's "Rows .." and initial score lines pass through gf.log
+        said.append(" ".join(str(x) for x in a))
+        plain_log(*a)
+    gf.log = keep
+    try:
+        gf.watch_reference(msa, out, T, 1, recs.append, "[pw_ref]")
+    finally:
+        gf.log = plain_log
+    fx["rows_line"] = next(l.split("[pw_ref] ", 1)[1] for l in said if l.startswith("[pw_ref] Rows "))
+    fx["initial_score_line"] = next(l.split("[pw_ref] initial ", 1)[1] for l in said if l.startswith("[pw_ref] initial "))
     r = recs[0]
     r["round"] = 1
     fx["round1"] = r

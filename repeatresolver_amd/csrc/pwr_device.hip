@@ -164,6 +164,7 @@ struct JobBufs {
     int src_start;                 // 1: a warm-up starts from the column of the base before it alone (k_fill_v3), 0: from the free start
     int smax, seg_rows, warm_cols; // at most smax segments per job, of about seg_rows own rows, warmed up over warm_cols columns of band movement
     int seg_budget, seg_minrows;   // segments all jobs of a batch may have together (dealt by length), none with fewer own rows than seg_minrows
+    int seg_balance;               // 1: the own parts are cut so that all segments of a job run about the same number of rows, warm-up included
     const int *rowids;             // the slab's rows (the plan of a job looks at the lengths of the batch's other jobs)
     int gstride;                   // rows per wave of a job's mailbox area
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
@@ -454,7 +455,9 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
                     if (kj >= 0) Lsum += st.rowlen[jb.rowids[kj]];
                 }
                 Lsum = max(Lsum, (long long)L);
-                S = min((int)((long long)jb.seg_budget * L / Lsum), L / max(16, jb.seg_minrows));
+                // (two alignment units of own rows at least: the own parts start at multiples of seg_align, and a segment
+                // without rows of its own is none)
+                S = min((int)((long long)jb.seg_budget * L / Lsum), L / max(max(16, jb.seg_minrows), 2 * jb.seg_align));
             }
         }
         S = max(1, min(S, jb.smax));
@@ -470,7 +473,36 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
     const int S = s_S, warm = s_warm;
     if (tid <= S) s_x[tid] = tid == S ? L : (int)(((long long)L * tid / S) & ~(long long)(jb.seg_align - 1));   // (a multiple of 16: the record is stored per 16 rows)
     __syncthreads();
-    {
+    // Where the own parts begin.  First in equal shares of the row; then -- "seg_balance" -- moved so that every segment has about
+    // the same number of rows to run, warm-up included: a launch ends with its longest segment, the first one has no warm-up at
+    // all, and a warm-up of so many COLUMNS is more rows where the row's bases sit closer together.  (The warm-ups of the moved
+    // boundaries are looked up again; they differ a little from the ones the shares were cut by, which is all the same to the
+    // results and nearly so to the balance.)
+    for (int it = 0; it < 2; ++it) {
+        if (it == 1) {
+            if (!jb.seg_balance || S < 3) break;
+            __shared__ int s_nx[SEG_MAX + 1], s_okb;
+            if (tid == 0) {
+                long long sumw = 0;
+                for (int s2 = 1; s2 < S; ++s2) sumw += s_x[s2] - s_xb[s2];
+                const int chain = (int)((L + sumw) / S);                // rows every segment should run
+                const int al = jb.seg_align, minown = max(2 * al, 32);
+                int x = 0, ok = 1;
+                s_nx[0] = 0;
+                for (int s2 = 0; s2 < S - 1; ++s2) {
+                    const int own = max(minown, chain - (s2 ? s_x[s2] - s_xb[s2] : 0));
+                    x = (x + own) & ~(al - 1);
+                    s_nx[s2 + 1] = x;
+                }
+                s_nx[S] = L;
+                for (int s2 = 0; s2 < S; ++s2) if (s_nx[s2 + 1] - s_nx[s2] < minown) ok = 0;   // (the last one takes what is left: too little -> equal shares)
+                s_okb = ok;
+            }
+            __syncthreads();
+            if (!s_okb) break;
+            if (tid <= S) s_x[tid] = s_nx[tid];
+            __syncthreads();
+        }
         // xb of segment s: the largest multiple of 16 below x_s whose row sits at least `warm` columns left of row x_s (Way[]
         // is increasing).  Sixteen threads per segment, a 16-ary search: three dependent loads instead of twelve (this share
         // would otherwise be the one its kernel waits for).
@@ -498,6 +530,7 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
         }
         if (li == 0 && sgi < S) s_xb[sgi] = (sgi == 0 || lo_c < 0) ? 0 : 16 * lo_c;
       }
+        __syncthreads();
     }
     __syncthreads();
     // cells of the rows [xb, xe): B each, less what the MSA's right edge cuts off the band (PW:1497) -- only the rows from
@@ -3728,11 +3761,13 @@ struct pwr_ctx {
     unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
     int wp_waves = 5;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane (5: measured best with segments side by side)
     int one_wg = 0;                       // k_fill_v3: the waves of a segment as one work-group (hand-over through LDS); 0: one work-group per wave
+    int one_wg_lds = 0;                   // ... with this many bytes of dynamic LDS on top (keeps other work-groups off its compute unit)
     int seg_rows = 160;                   // k_fill_v3: a DP is filled in segments of about this many rows, side by side (0: in one piece)
     int seg_align = 16;                   // ... whose own parts start at multiples of this many rows (16 / 32 / 64)
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
     int seg_budget = 0;                   // > 0: this many for all the jobs of a batch together, dealt by length (measured slower; 0: seg_rows rows each)
     int seg_minrows = 64;                 // ... none with fewer own rows than this
+    int seg_balance = 1;                  // ... cut so that every segment runs about as many rows as the others, its warm-up included (0: equal own parts)
     int split_rank = 0, split_world = 1;  // pwr_split_*: this context is replica split_rank of split_world (one per GPU)
     int split_k0 = 0, split_kend = 0;     // ... rows of the slab in progress
     int src_start = 1;                    // ... from the column of the base before the warm-up's first row alone (0: from the free start)
@@ -3957,7 +3992,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     if ((rc = dmalloc(c, &jb.lastM, (size_t)njobs * jb.NC))) return rc;
     jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
     jb.seg_align = c->seg_align;
-    jb.seg_budget = c->seg_budget; jb.seg_minrows = c->seg_minrows;
+    jb.seg_budget = c->seg_budget; jb.seg_minrows = c->seg_minrows; jb.seg_balance = c->seg_balance;
     jb.rowids = c->d_rowids;
     jb.seg_rows = c->fill_mode == 4 ? c->seg_rows : 0;
     jb.src_start = c->src_start;
@@ -4266,12 +4301,14 @@ static int launch_fill(pwr_ctx *c, int njobs)
         const dim3 grid(8, c->wp_waves, (nv + 7) / 8);
         const bool wg1 = c->one_wg && c->wp_waves <= 9 && c->B <= 1024;
         if (wg1) {
-            // the waves of a segment as one work-group (LDS hand-over)
-            if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4, true>), dim3(nv), dim3(5 * 64), 0, c->stream, c->st, c->jb);
-            else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3, true>), dim3(nv), dim3(8 * 64), 0, c->stream, c->st, c->jb);
-            else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6, true>), dim3(nv), dim3(4 * 64), 0, c->stream, c->st, c->jb);
-            else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8, true>), dim3(nv), dim3(3 * 64), 0, c->stream, c->st, c->jb);
-            else hipLaunchKernelGGL((k_fill_v3<9, 2, true>), dim3(nv), dim3(9 * 64), 0, c->stream, c->st, c->jb);
+            // the waves of a segment as one work-group (LDS hand-over); "onewg_lds" bytes of dynamic LDS on top keep other
+            // work-groups off the segment's compute unit (experiment: a CU to itself, one wave per SIMD with waves = 4)
+            const size_t pad = (size_t)c->one_wg_lds;
+            if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4, true>), dim3(nv), dim3(5 * 64), pad, c->stream, c->st, c->jb);
+            else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3, true>), dim3(nv), dim3(8 * 64), pad, c->stream, c->st, c->jb);
+            else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6, true>), dim3(nv), dim3(4 * 64), pad, c->stream, c->st, c->jb);
+            else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8, true>), dim3(nv), dim3(3 * 64), pad, c->stream, c->st, c->jb);
+            else hipLaunchKernelGGL((k_fill_v3<9, 2, true>), dim3(nv), dim3(9 * 64), pad, c->stream, c->st, c->jb);
         }
         else if (c->wp_waves == 17) hipLaunchKernelGGL((k_fill_v3<17, 1, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
@@ -4766,10 +4803,12 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "fill_epoch")) { if (value < 0 || value >= (1 << 15)) return PWR_ERR_ARG; c->fill_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "trace_epoch")) { if (value < 0 || value >= (1 << 14)) return PWR_ERR_ARG; c->trace_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "onewg")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->one_wg = (int)value; return PWR_OK; }
+    if (!strcmp(key, "onewg_lds")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->one_wg_lds = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_rows")) { if (c->on_device || value < 0 || value > 1000000) return PWR_ERR_ARG; c->seg_rows = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_align")) { if (c->on_device || (value != 16 && value != 32 && value != 64)) return PWR_ERR_ARG; c->seg_align = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_budget")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->seg_budget = (int)value; c->jb.seg_budget = (int)value; return PWR_OK; }
+    if (!strcmp(key, "seg_balance")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->seg_balance = (int)value; c->jb.seg_balance = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_minrows")) { if (value < 16 || value > 100000) return PWR_ERR_ARG; c->seg_minrows = (int)value; c->jb.seg_minrows = (int)value; return PWR_OK; }
     if (!strcmp(key, "src_start")) { if (c->on_device || value < 0 || value > 1) return PWR_ERR_ARG; c->src_start = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_adapt")) { if (c->on_device || value < 0 || value > 1) return PWR_ERR_ARG; c->warm_adapt = (int)value; return PWR_OK; }
@@ -4797,6 +4836,7 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "seg_max")) *value = c->seg_max;
     else if (!strcmp(key, "seg_budget")) *value = c->seg_budget;
     else if (!strcmp(key, "seg_minrows")) *value = c->seg_minrows;
+    else if (!strcmp(key, "seg_balance")) *value = c->seg_balance;
     else if (!strcmp(key, "warm_pct")) *value = c->warm_pct;
     else if (!strcmp(key, "src_start")) *value = c->src_start;
     else if (!strcmp(key, "warm_adapt")) *value = c->warm_adapt;

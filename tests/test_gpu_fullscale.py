@@ -174,6 +174,68 @@ def test_config2_cli_rounds_against_the_reference(tmp_path):
     assert h.hexdigest() == fx["rounds"][n - 1]["output_sha256"]
 
 
+def test_bench_input_is_the_references_own_msa_and_round_one(tmp_path):
+    """The MSA `bench.py` runs by default (--input pipeline), pinned by the REFERENCE end to end
+    (tests/golden/pipeline_tree_default_round1.json, oracle/gen_pipeline_fixture.py): the reads `pipeline.initial_msa` keeps were
+    written as FASTA and aligned by the reference's own InitialAligner (an hour of six cores), its MSA then realigned for one
+    round by the reference's PW_ReAligner (40 minutes).  Here: (1) the GPU InitialAligner + Building_MSA reproduce that MSA
+    byte for byte at full size -- 13 594 reads, 4 * 10^12 cells: SURVEY N2 against the reference itself; (2) the drop-in binary
+    reproduces the score lines and the bytes of the file the reference rewrote after round 1 (PW:1741)."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.pipeline import initial_msa
+    from repeatresolver_amd.realigner import run_file, write_msa
+    with open(os.path.join(GOLDEN, "pipeline_tree_default_round1.json")) as f:
+        fx = json.load(f)
+    rows, info = initial_msa(dg.CONFIGS["tree_default"])
+    assert (info["reads"], info["bases"], info["template"]) == (fx["reads"], fx["bases"], fx["template"]), "the seeded generator drifted"
+    assert (len(rows), len(rows[0])) == (fx["msa_rows"], fx["msa_columns"])
+    assert _sha_rows(rows) == fx["msa_sha256"]
+    ip, op = str(tmp_path / "in.msa"), str(tmp_path / "out.msa")
+    write_msa(ip, rows)
+    del rows
+    rc, lines = run_file(ip, op, bandwidth=fx["bandwidth"], max_rounds=1)
+    assert rc == 0
+    r1 = fx["round1"]
+    assert [l for l in lines if l.startswith("Rows ")] == [fx["rows_line"]]
+    got = [l for l in lines if l.startswith("OverallScore")]
+    assert got[:2] == [fx["initial_score_line"], r1["score_line"]], got
+    assert r1["improved"]
+    h = hashlib.sha256()
+    with open(op, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    assert h.hexdigest() == r1["output_sha256"]
+    assert os.path.getsize(op) == r1["rows"] * (r1["columns"] + 1)
+
+
+def test_config3_one_full_round_against_the_port():
+    """BASELINE.json configs[2] (Distributed, 200 copies, 60x: 40 195 rows -- more than the reference's Max_Seq_Anzahl 18000,
+    PW:17, so the reference cannot hold it and the CPU port, itself pinned to the reference by tests/golden/*.in.gz, is the only
+    possible checker): one FULL round, score, width, cell count and sha256 of the exported text against
+    tests/golden/distributed_stress_round1.json (PORT-made, oracle/gen_pipeline_fixture.py --config3, 40 CPU-minutes)."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    with open(os.path.join(GOLDEN, "distributed_stress_round1.json")) as f:
+        fx = json.load(f)
+    rows = [bytes(r) for r in dg.make_msa("distributed_stress")]
+    assert (len(rows), len(rows[0])) == (fx["input_rows"], fx["input_columns"])
+    assert _sha_rows(rows) == fx["input_sha256"], "the seeded generator drifted"
+    g = PWReAligner(rows, bandwidth=fx["bandwidth"])
+    del rows
+    g.trim_ends()
+    assert g.dims() == (fx["input_rows"], fx["columns_after_trim"])
+    assert g.total_score() == fx["initial_score"]
+    g.realign_round()
+    r1 = fx["round1"]
+    assert g.total_score() == r1["score"]
+    assert g.dims() == (r1["rows"], r1["columns"])
+    st = g.stats()
+    assert st["cells_reference"] == r1["cells"]
+    assert st["stalls"] == 0 and st["rows_committed"] > 40000
+    assert _sha_rows(g.export_rows()) == r1["output_sha256"]
+    g.close()
+
+
 def test_config4_sections_of_the_benchmark_msa(oracle):
     """BASELINE.json configs[3] at its real size: the benchmark MSA after one realignment round (checked against the
     reference's digest of that round) is cut at its Window.py boundaries (parts = 6, Window.py:41-60); all six sections are

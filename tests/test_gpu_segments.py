@@ -21,7 +21,7 @@ def test_segmented_fill_row_by_row(name, bw, rounds, seg_rows, warm_pct, src_sta
     whether a warm-up starts from the column of the base before it alone (src_start 1, the default) or from the free start
     of PW:265 (0), and with a warm-up of 1.1 bandwidths that only the former can get away with (what it cannot is caught
     by the check and repeated)."""
-    _row_by_row(name, bw, rounds, oracle, seg_rows=seg_rows, seg_max=64, warm_pct=warm_pct, src_start=src_start, seg_budget=0)
+    _row_by_row(name, bw, rounds, oracle, seg_rows=seg_rows, seg_max=64, warm_pct=warm_pct, src_start=src_start, seg_budget=0, seg_balance=seg_rows == 128)
 
 
 @pytest.mark.parametrize("budget,minrows,smax", [(200, 64, 256), (48, 16, 256), (400, 32, 256), (7, 64, 5)])
@@ -104,7 +104,7 @@ def test_cells_computed_count_the_warm_up_rows(budget, minrows, oracle):
     rows = split_rows(golden_input("toy_b_b1000"))
     bw, H, sr, smax, wp = 1000, 500, 128, 64, 150
     warm_cols = bw * wp // 100 + 2
-    g = PWReAligner(rows, bandwidth=bw, window=1, seg_rows=sr, seg_max=smax, warm_pct=wp, warm_adapt=0, seg_budget=budget, seg_minrows=minrows)   # (a fixed warm-up: the plan below)
+    g = PWReAligner(rows, bandwidth=bw, window=1, seg_rows=sr, seg_max=smax, warm_pct=wp, warm_adapt=0, seg_budget=budget, seg_minrows=minrows, seg_balance=0)   # (a fixed warm-up, equal own parts: the plan below)
     g.trim_ends()
     h = oracle.create(rows, bw)
     lib = oracle.lib
@@ -119,7 +119,7 @@ def test_cells_computed_count_the_warm_up_rows(budget, minrows, oracle):
         W = lib.pwo_dbg_W_at_fill(h)
         way = np.ctypeslib.as_array(lib.pwo_dbg_way(h), (L,)).astype(np.int64)
         cells = np.minimum(bw, W - np.maximum(0, way - H))
-        S = max(1, min((L + sr // 2) // sr, smax, L // 128)) if budget == 0 else max(1, min(budget, L // max(16, minrows), smax))
+        S = max(1, min((L + sr // 2) // sr, smax, L // 128)) if budget == 0 else max(1, min(budget, L // max(16, minrows, 32), smax))
         xs = [(L * s // S) & ~15 for s in range(S)] + [L]
         for s in range(S):
             xb = 0
