@@ -142,9 +142,10 @@ void pwr_snapshot_free(pwr_snapshot *snap);
  *               (default 64), none with more segments than seg_max; default 0 = about seg_rows rows per segment whatever the
  *               batch (a budget of 160-320 was measured 7-20 % slower: every further segment brings its own warm-up)
  *   "seg_balance"
- *               1 (default): the own parts of a job's segments are cut so that every segment runs about the same number of rows,
- *               its warm-up included (the first has none; a warm-up of so many columns is more rows where the bases sit closer);
- *               0: equal own parts
+ *               1: the own parts of a job's segments are cut so that every segment runs about the same number of rows, its warm-up
+ *               included (the first has none; a warm-up of so many columns is more rows where the bases sit closer); default 0 =
+ *               equal own parts (the balanced cut was measured 5-12 % slower: the first segment's long own part, whose rows make
+ *               the record, becomes the launch's last)
  *   "ptrace"    traceback kernel: 2 = k_trace_blk (default: one wave per 64 rows, no hand-over chain), 1 = k_trace_par (64 chunks
  *               handing over top-down), 0 = k_trace_wp (one wave per job)
  *   "slack"     spare column capacity kept when the device arrays are (re)allocated

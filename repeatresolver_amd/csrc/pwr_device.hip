@@ -485,14 +485,14 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
             if (tid == 0) {
                 long long sumw = 0;
                 for (int s2 = 1; s2 < S; ++s2) sumw += s_x[s2] - s_xb[s2];
-                const int chain = (int)((L + sumw) / S);                // rows every segment should run
+                // (a row of the own part costs about 1.2 rows of a warm-up: it makes the record)
+                const long long chain12 = (12LL * L + 10LL * sumw) / S;    // what every segment should cost, in tenths of a warm-up row
                 const int al = jb.seg_align, minown = max(2 * al, 32);
-                int x = 0, ok = 1;
-                s_nx[0] = 0;
+                int x = 0, ok = 1;                                     // (x: the exact position; the boundaries are rounded down from it,
+                s_nx[0] = 0;                                           // so the roundings do not add up in the last segment)
                 for (int s2 = 0; s2 < S - 1; ++s2) {
-                    const int own = max(minown, chain - (s2 ? s_x[s2] - s_xb[s2] : 0));
-                    x = (x + own) & ~(al - 1);
-                    s_nx[s2 + 1] = x;
+                    x += max(minown, (int)((chain12 - 10LL * (s2 ? s_x[s2] - s_xb[s2] : 0)) / 12));
+                    s_nx[s2 + 1] = min(x, L) & ~(al - 1);
                 }
                 s_nx[S] = L;
                 for (int s2 = 0; s2 < S; ++s2) if (s_nx[s2 + 1] - s_nx[s2] < minown) ok = 0;   // (the last one takes what is left: too little -> equal shares)
@@ -3767,7 +3767,7 @@ struct pwr_ctx {
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
     int seg_budget = 0;                   // > 0: this many for all the jobs of a batch together, dealt by length (measured slower; 0: seg_rows rows each)
     int seg_minrows = 64;                 // ... none with fewer own rows than this
-    int seg_balance = 1;                  // ... cut so that every segment runs about as many rows as the others, its warm-up included (0: equal own parts)
+    int seg_balance = 0;                  // 1: ... cut so that every segment runs about as many rows as the others, its warm-up included (measured slower)
     int split_rank = 0, split_world = 1;  // pwr_split_*: this context is replica split_rank of split_world (one per GPU)
     int split_k0 = 0, split_kend = 0;     // ... rows of the slab in progress
     int src_start = 1;                    // ... from the column of the base before the warm-up's first row alone (0: from the free start)

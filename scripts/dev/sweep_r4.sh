@@ -1,7 +1,7 @@
 # dev (GPU box): bench over option sets given as lines on stdin-free list below
 run() {
   o="$1"
-  args=""; for kv in $o; do case $kv in waves=*) args="$args --waves ${kv#waves=}";; *) args="$args --opt $kv";; esac; done
+  args=""; for kv in $o; do case $kv in waves=*) args="$args --waves ${kv#waves=}";; window=*) args="$args --window ${kv#window=}";; *) args="$args --opt $kv";; esac; done
   python3 bench.py --steps 8 --warmup 3 --no-cpu-baseline $args > gpurun_out/r4_sw.json 2> gpurun_out/r4_sw.err || { echo "$o FAILED"; tail -3 gpurun_out/r4_sw.err; return; }
   python3 -c "
 import json; d=json.load(open('gpurun_out/r4_sw.json')); print('$o', 'ms/step %.1f value %.3e launch_ms %.4f useful %.3f cpb %.3f fails %d stalls %d warm %d' % (d['ms_per_step'], d['value'], d['roofline']['avg_launch_ms'], d['config']['useful_frac'], d['config']['commits_per_batch'], d['config']['seg_fails'], d['config']['stalls'], d['config']['options']['warm_now']))" | tee -a gpurun_out/r4_sweep.log
