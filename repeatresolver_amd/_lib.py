@@ -42,6 +42,14 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C repeatresolver_amd/csrc`.  There is no CPU fallback for the product path.")
+    # Load order matters in a process that also uses torch: torch brings its own copy of the HIP runtime, libpwr.so is linked
+    # against the system's, and the dynamic loader gives the process whichever copy came first under that name.  With the
+    # system's first, torch.cuda later fails to initialise ("No HIP GPUs are available" -- found when a test module that touches
+    # torch ran after modules that had loaded libpwr.so); with torch's first both work.  So torch goes first when it is there.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     lib.pwr_create.restype = ci

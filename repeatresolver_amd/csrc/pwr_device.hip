@@ -2654,8 +2654,10 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
 // (exit field all ones: the pass broke off inside the chunk)
 // ---------------------------------------------------------------------------------------------
 #define TB_W 4                                          // chunks per work-group
+#ifndef TB_C
 #define TB_C 32                                         // rows per chunk (one lane per row; a row of the trace costs ~290 ns of dependent
                                                         // instructions, so a chunk half as long is traced in half the time: 64 -> 32 rows, 30 -> 20 us)
+#endif
 #define TB_BROKE 0x1fffffu
 #define TB_WORD(TAG, FLAG, CNT, ARR, EXF) (((unsigned long long)((TAG) & 0x3fffu) << 50) | ((unsigned long long)(FLAG) << 48) | ((unsigned long long)((CNT) & 0x7f) << 41) | \
                                            ((unsigned long long)(((ARR) + 1) & 0xfffff) << 21) | (unsigned long long)((EXF) & 0x1fffffu))
@@ -2996,7 +2998,8 @@ struct CommitEv { int key[EVCAP], dl[EVCAP], skey[EVCAP], scum[EVCAP], seg_lo[EV
 __global__ __launch_bounds__(COMMIT_NT) void k_commit_scan(DState st, JobBufs jb, int njobs)
 {
     __shared__ unsigned sh[COMMIT_NT / 64];
-    __shared__ int s_cpre[COMMIT_NT];
+    constexpr int CPQ = (PWR_MAX_SEQ_LENGTH / TB_C + COMMIT_NT) / COMMIT_NT;   // chunks of the traceback per thread of the prefix below
+    __shared__ int s_cpre[COMMIT_NT * CPQ];
     __shared__ int s_ov[MAXJ], s_ovlo[MAXJ], s_ovhi[MAXJ], s_nov;
     const int job = blockIdx.x, g = blockIdx.y, tid = threadIdx.x;
     const JobMeta *m = &jb.meta[job];
@@ -3005,7 +3008,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_scan(DState st, JobBufs jb
     const int k = m->k, L = m->L;
     if (!m->changed && st.nbrk[k] == 0) return;           // the traceback left every base where it was (k_trace_blk): nothing changes
     const int nch = (L + TB_C - 1) / TB_C;
-    const bool chunked = jb.trace_blk != 0 && nch <= COMMIT_NT;     // k_trace_blk counted the 'up' moves of every TB_C rows
+    const bool chunked = jb.trace_blk != 0 && nch <= COMMIT_NT * CPQ;   // k_trace_blk counted the 'up' moves of every TB_C rows
     const int G = (chunked && L >= 64 * CS_G) ? CS_G : 1;
     if (g >= G) return;
     CommitJob *cj = &jb.cjob[job];
@@ -3045,10 +3048,14 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_scan(DState st, JobBufs jb
     for (int y = Y0 + tid; y < Y1; y += COMMIT_NT) mark2[y - lo] = 0;
     if (chunked) {
         const unsigned long long *hand = jb.gtr + (size_t)job * jb.trk;
-        const unsigned mine = tid < nch ? (unsigned)((hand[tid] >> 41) & 0x7full) : 0u;
+        unsigned cq[CPQ], mine = 0;
+#pragma unroll
+        for (int q = 0; q < CPQ; ++q) { const int ch = tid * CPQ + q; cq[q] = ch < nch ? (unsigned)((hand[ch] >> 41) & 0x7full) : 0u; mine += cq[q]; }
         unsigned tot;
         const unsigned incl = block_incl_add<COMMIT_NT>(mine, sh, tot);
-        s_cpre[tid] = (int)(incl - mine);
+        unsigned run = incl - mine;
+#pragma unroll
+        for (int q = 0; q < CPQ; ++q) { s_cpre[tid * CPQ + q] = (int)run; run += cq[q]; }
     }
     __syncthreads();
     const int nov = s_nov;
