@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--sections", type=int, default=None,
                     help="Window.py parts the MSA is cut into (N > 1: default 6 = configs[3]; more parts than ranks are dealt by bases, longest first).  "
                          "With --gpus 1 the parts run as that many contexts side by side on the ONE GPU, each on its own stream: config 4's aggregate rate per GPU")
+    ap.add_argument("--only-section", type=int, default=None, help="--gpus 1 --sections P: run only this section (what ONE section's chain reaches with the GPU to itself)")
     ap.add_argument("--window", type=int, default=None)
     ap.add_argument("--split", default="sections", choices=["sections", "rows"],
                     help="N > 1: sections = configs[3], the MSA cut into Window.py sections dealt to the ranks (default); rows = the WHOLE MSA on every "
@@ -181,7 +182,7 @@ def main():
             r = min(range(world), key=lambda r: (load[r], r))
             owner[p] = r
             load[r] += cost[p]
-        units = [(f"section {p} columns [{bounds[p]},{bounds[p + 1]})", secs[p]) for p in range(len(secs)) if owner[p] == rank]
+        units = [(f"section {p} columns [{bounds[p]},{bounds[p + 1]})", secs[p]) for p in range(len(secs)) if owner[p] == rank and (args.only_section is None or p == args.only_section)]
         owned = [[p for p in range(len(secs)) if owner[p] == r] for r in range(world)]
         note(f"sections {bounds} dealt as {owner}: " + ", ".join(f"rank {r} {owned[r] or 'IDLE'} ({load[r]} bases)" for r in range(world)))
     ctxs = []
@@ -272,7 +273,7 @@ def main():
         made = ("the reads cut to their repeat part, aligned into the template by the InitialAligner (GPU, placements identical to the reference's) "
                 "and stacked by Building_MSA: the pipeline's real input" if args.input == "pipeline" else
                 "the MSA stacks the TRUE read-to-template alignments with InitialAligner's layout rule -- it is not an InitialAligner product")
-        if world == 1 and len(ctxs) > 1:
+        if world == 1 and args.sections:
             wl = (f"{cfg.name} ({args.workload}; {made}) -> {T} rows x {W0} columns cut into {args.sections} Window.py sections {bounds} (BASELINE.json configs[3]), "
                   f"ALL of them on this one GPU as {len(ctxs)} contexts side by side, each on its own stream; one step = the next {T // args.slabs} rows of "
                   f"every section; value = the sections' reference cells together / wall time")
@@ -336,7 +337,7 @@ def main():
         }
         if per_rank is not None:
             out["per_rank"] = per_rank
-        if world == 1 and len(ctxs) > 1:
+        if world == 1 and args.sections:
             out["per_section"] = [{"section": units[ci][0], "seconds_in_calls": round(ctx_seconds[ci], 3), "cells": g.stats()["cells_reference"],
                                    "stalls": g.stats()["stalls"], "batches": g.stats()["batches"]} for ci, g in enumerate(ctxs)]
         if world == 1 and not args.no_cpu_baseline and final:

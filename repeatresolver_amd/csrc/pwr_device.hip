@@ -3769,6 +3769,7 @@ struct pwr_ctx {
     int wp_waves = 5;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane (5: measured best with segments side by side)
     int one_wg = 0;                       // k_fill_v3: the waves of a segment as one work-group (hand-over through LDS); 0: one work-group per wave
     int one_wg_lds = 0;                   // ... with this many bytes of dynamic LDS on top (keeps other work-groups off its compute unit)
+    int fill_lds = 0;                     // experiment: dynamic LDS per work-group of the default fill (bounds the work-groups per compute unit)
     int seg_rows = 160;                   // k_fill_v3: a DP is filled in segments of about this many rows, side by side (0: in one piece)
     int seg_align = 16;                   // ... whose own parts start at multiples of this many rows (16 / 32 / 64)
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
@@ -4318,7 +4319,7 @@ static int launch_fill(pwr_ctx *c, int njobs)
             else hipLaunchKernelGGL((k_fill_v3<9, 2, true>), dim3(nv), dim3(9 * 64), pad, c->stream, c->st, c->jb);
         }
         else if (c->wp_waves == 17) hipLaunchKernelGGL((k_fill_v3<17, 1, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
-        else if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->wp_waves == 5) hipLaunchKernelGGL((k_fill_v3<5, 4, false>), grid, dim3(128), (size_t)c->fill_lds, c->stream, c->st, c->jb);
         else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
@@ -4810,6 +4811,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "fill_epoch")) { if (value < 0 || value >= (1 << 15)) return PWR_ERR_ARG; c->fill_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "trace_epoch")) { if (value < 0 || value >= (1 << 14)) return PWR_ERR_ARG; c->trace_epoch = (unsigned)value; return PWR_OK; }
     if (!strcmp(key, "onewg")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->one_wg = (int)value; return PWR_OK; }
+    if (!strcmp(key, "fill_lds")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->fill_lds = (int)value; return PWR_OK; }
     if (!strcmp(key, "onewg_lds")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->one_wg_lds = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_rows")) { if (c->on_device || value < 0 || value > 1000000) return PWR_ERR_ARG; c->seg_rows = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_align")) { if (c->on_device || (value != 16 && value != 32 && value != 64)) return PWR_ERR_ARG; c->seg_align = (int)value; return PWR_OK; }
