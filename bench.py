@@ -240,7 +240,7 @@ def main():
         """Builds and prints THE json line (rank 0)."""
         st = stats_sum() if ctxs else {"cells_reference": 0, "cells_computed": 0, "fill_ms": 0.0, "fill_launches": 0, "fill_launches_timed": 0,
                                        "rows_committed": 0, "rows_recomputed": 0, "batches": 0, "rows_changed": 0, "reject_reason": [0, 0, 0, 0],
-                                       "stalls": 0, "rows_wide": 0, "rows_ahead": 0, "seg_jobs": 0, "segs": 0, "seg_fails": 0}
+                                       "stalls": 0, "rows_wide": 0, "rows_ahead": 0, "seg_jobs": 0, "segs": 0, "seg_fails": 0, "rows_jumped": 0}
         cells = float(st["cells_reference"])
         tmax, csum, tmin = dt, cells, dt
         per_rank = None
@@ -308,11 +308,11 @@ def main():
                        "rows_committed": st["rows_committed"], "rows_recomputed": st["rows_recomputed"], "batches": st["batches"],
                        "rows_changed": st["rows_changed"], "reject_reason": st["reject_reason"],
                        # self-audit: a time-out repeated by the stand-in kernel, a 64-bit fill or a failed segment check would show here
-                       "stalls": st["stalls"], "rows_wide": st["rows_wide"], "rows_ahead": st["rows_ahead"],
+                       "stalls": st["stalls"], "rows_wide": st["rows_wide"], "rows_ahead": st["rows_ahead"], "rows_jumped": st.get("rows_jumped", 0),
                        "useful_frac": (st["cells_reference"] / st["cells_computed"]) if st["cells_computed"] else None,
                        "commits_per_batch": (st["rows_committed"] / st["batches"]) if st["batches"] else None,
                        "seg_jobs": st["seg_jobs"], "segs": st["segs"], "seg_fails": st["seg_fails"],
-                       "options": {k_: ctxs[0].get_option(k_) for k_ in ("window", "fill", "waves", "spec_len", "seg_rows", "seg_max", "warm_pct", "src_start", "warm_adapt", "warm_min_pct", "warm_down_pm", "warm_up_pm", "warm_now")} if ctxs else None,
+                       "options": {k_: ctxs[0].get_option(k_) for k_ in ("window", "fill", "waves", "spec_len", "seg_rows", "seg_max", "warm_pct", "src_start", "warm_adapt", "warm_min_pct", "warm_down_pm", "warm_up_pm", "warm_now", "plan_ahead", "plan_slack", "plan_evrate_x100", "evrate_x100")} if ctxs else None,
                        "generate_s": round(gen_s, 1), "input": args.input, "initial_aligner": ia_info, "complete": bool(final)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

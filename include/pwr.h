@@ -36,6 +36,10 @@ extern "C" {
 #define PWR_ERR_STALL (-9)       /* a wave of the fill kernel timed out waiting for a neighbour work-group (GPU shared or
                                     oversubscribed) AND the geometry has no one-work-group form to repeat the job with
                                     ("waves" = 17); with the other geometries a stall only costs time (pwr_stats.stalls) */
+#define PWR_ERR_ORDER (-10)      /* a row that was realigned ahead of rows outside its batch ("plan_ahead") was found, at the gather of
+                                    one of those rows, to lie within reach of it after all: the two do not commute and the state is
+                                    not the reference's.  Never reached with the gap and the event rate rows jump at; the check
+                                    exists so that it could not go unnoticed.  Rerun with "plan_ahead" 0. */
 
 #define PWR_MAX_BANDWIDTH 2000   /* PW:14 */
 #define PWR_MAX_SEQ_LENGTH 35000 /* PW:16 */
@@ -63,6 +67,7 @@ typedef struct pwr_stats {
     uint64_t seg_jobs;          /* fills that ran as several segments side by side (k_fill_v3) */
     uint64_t segs;              /* ... and the segments they were cut into */
     uint64_t seg_fails;         /* ... of which this many failed the check of a segment's start and were repeated in one piece */
+    uint64_t rows_jumped;       /* commits of rows picked ahead of rows that were not in their batch ("plan_ahead") */
 } pwr_stats;
 
 /* Replaces MMA_Einlesen (PW:93-241) for an in-memory matrix: `text` holds rows*width characters,
@@ -141,6 +146,12 @@ void pwr_snapshot_free(pwr_snapshot *snap);
  *               row beside two short ones is cut finer than one of three long rows --, none with fewer own rows than seg_minrows
  *               (default 64), none with more segments than seg_max; default 0 = about seg_rows rows per segment whatever the
  *               batch (a budget of 160-320 was measured 7-20 % slower: every further segment brings its own warm-up)
+ *   "plan_ahead"
+ *               1 (default): the speculative rows of a batch are picked by the batch before it -- first the rows among the next 64
+ *               whose band interval keeps more than 2048 columns from that of every uncommitted row before them (they commute with
+ *               all of those, so they commit in this very batch), then the next rows in order as before; rows are picked ahead only
+ *               while a commit opens / empties fewer than 12 columns on average, and every row that was jumped checks at its gather
+ *               that the gap has held (PWR_ERR_ORDER otherwise); 0: the next rows in order (round 3).  "window" above 16: in order.
  *   "seg_balance"
  *               1: the own parts of a job's segments are cut so that every segment runs about the same number of rows, its warm-up
  *               included (the first has none; a warm-up of so many columns is more rows where the bases sit closer); default 0 =

@@ -14,7 +14,8 @@ class PwrStats(ctypes.Structure):
                 ("batches", ctypes.c_uint64), ("rows_changed", ctypes.c_uint64),
                 ("reject_reason", ctypes.c_uint64 * 4), ("fill_launches_timed", ctypes.c_uint64),
                 ("stalls", ctypes.c_uint64), ("rows_ahead", ctypes.c_uint64), ("rows_wide", ctypes.c_uint64),
-                ("seg_jobs", ctypes.c_uint64), ("segs", ctypes.c_uint64), ("seg_fails", ctypes.c_uint64)]
+                ("seg_jobs", ctypes.c_uint64), ("segs", ctypes.c_uint64), ("seg_fails", ctypes.c_uint64),
+                ("rows_jumped", ctypes.c_uint64)]
 
 
 # every symbol include/pwr.h declares

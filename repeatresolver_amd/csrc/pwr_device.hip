@@ -72,6 +72,13 @@ struct Hdr {                       // lives in device memory, one per context
     // (measured).
     // Results never depend on it.  warm_step 0: fixed length (JobBufs::warm_cols).
     int warm_cur, warm_lo, warm_hi, warm_step, warm_up;   // (warm_up: columns a failure puts back on)
+    // Rows picked AHEAD of rows that are not in their batch (k_commit_finish): bit b of jumpmask = row next_row + b is one; the
+    // structural events (columns opened / emptied) committed so far and their running mean per commit: a row jumps only while
+    // 64 commits' worth of events stay far below the gap it keeps, and every row that was jumped over checks at its gather that
+    // the gap has held (k_gather_a) -- exactness is checked, not assumed.
+    unsigned long long jumpmask;
+    unsigned long long events_total, rows_jumped;
+    float evrate; int pad1;
     unsigned long long dbg[32];    // phase timers of the traceback (10 ns ticks), only written by builds with -DPWR_DIAG
 };
 
@@ -117,7 +124,17 @@ struct DState {
     int *nbrk;                     // [T] cleared by the row's first commit
     int *inscnt;                   // scratch [colcap], kept all-zero between commits
     int *newidx;                   // scratch [colcap]
+    // The rows of the NEXT batch, picked by the batch before it (k_commit_finish): [0] 1 = the list is valid (0: the next rows in
+    // order), [1 + j] offset of job j's row from Hdr::next_row, [1 + PLAN_MAX + j] for a row picked AHEAD of rows that are not
+    // in the batch: its distance in columns to the nearest of their intervals (INT_MAX for the rows taken in order).
+    int *bplan;
 };
+#define PLAN_MAX 16                 // jobs a planned batch may have ("window" beyond that: rows in order)
+#define JR_BASE (1 + 2 * PLAN_MAX)  // behind the plan: one record per row that jumped, at (row index & 63): {events_total at its commit,
+                                    // columns of its interval left of its first base, right of its last base (own new columns included), -}
+#define BPLAN_WORDS (JR_BASE + 64 * 4)
+#define PLAN_EVRATE_MAX 12.0f       // rows jump only while a commit opens / empties fewer columns than this on average
+#define PLAN_SLACK 2048               // a row is picked ahead only if its interval keeps this many columns (+ 2) from every row it jumps
 
 // A DP is filled in SEGMENTS that run side by side (k_fill_v3): segment s owns the DP rows [xown, xe) and starts WARM rows
 // earlier, at xb, from a start of its own (one cell: the column of the base before row xb; or the free start of PW:265, as if
@@ -165,6 +182,8 @@ struct JobBufs {
     int smax, seg_rows, warm_cols; // at most smax segments per job, of about seg_rows own rows, warmed up over warm_cols columns of band movement
     int seg_budget, seg_minrows;   // segments all jobs of a batch may have together (dealt by length), none with fewer own rows than seg_minrows
     int seg_balance;               // 1: the own parts are cut so that all segments of a job run about the same number of rows, warm-up included
+    int plan_ahead;                // 1: the rows of a batch are picked by the batch before it: rows that commute with every row before them first
+    int plan_slack, plan_evrate_x100;   // ... which keep more than this many columns from them; only while a commit opens / empties fewer columns than this / 100 on average
     const int *rowids;             // the slab's rows (the plan of a job looks at the lengths of the batch's other jobs)
     int gstride;                   // rows per wave of a job's mailbox area
     unsigned tagbase;              // launch epoch << 17: tags of this launch are tagbase | (row + 1)
@@ -305,13 +324,16 @@ __device__ __forceinline__ const int *cur_order(const DState &st)
 struct GatherPart { unsigned long long ucost, cells; unsigned sum4, maxS, lastcov, tag; };   // what a share contributes, tag = launch
 
 // the job's row: the job-th row from next_row on that was not committed ahead of order already; -1: no such job in this batch
-__device__ __forceinline__ int gather_row_of(const Hdr *hd, int job, int *boff_out)
+__device__ __forceinline__ int gather_row_of(const Hdr *hd, const int *bplan, int job, int *boff_out)
 {
     int boff = 0;
-    const unsigned long long ah = hd->ahead;
-    int cnt = -1;
-    for (boff = 0; boff < 64; ++boff) if (!((ah >> boff) & 1ull) && ++cnt == job) break;
-    if (boff == 64) boff = 64 + (job - cnt - 1);
+    if (bplan[0] && job < PLAN_MAX) boff = bplan[1 + job];                       // picked by the batch before (k_commit_finish)
+    else {
+        const unsigned long long ah = hd->ahead;
+        int cnt = -1;
+        for (boff = 0; boff < 64; ++boff) if (!((ah >> boff) & 1ull) && ++cnt == job) break;
+        if (boff == 64) boff = 64 + (job - cnt - 1);
+    }
     *boff_out = boff;
     const int kk = hd->next_row + boff;
     if (hd->status != 0 || hd->need_grow || job >= hd->nb || kk >= hd->row_end) return -1;
@@ -326,7 +348,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, c
     JobMeta *m = &jb.meta[job];
     const Hdr *hd = st.hdr;
     int boff;
-    const int kk = gather_row_of(hd, job, &boff);
+    const int kk = gather_row_of(hd, st.bplan, job, &boff);
     if (g == 0) {
         // what the commit of this batch will note about the job (k_commit_scan) starts from nothing
         const int nj = (int)gridDim.x;
@@ -349,6 +371,24 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, c
     const int a0 = max(0, way0 - H), aL = max(0, wayL - H);
     const int lo = max(0, a0 - 1), hi = min(W - 1, aL + B - 1);
     const int n = hi - lo + 1;
+    if (g == 0 && tid < 64 && hd->jumpmask != 0ull) {
+        // Rows that were committed AHEAD of this one although it was not in their batch (picked by k_commit_finish because their
+        // intervals kept a wide gap from it): has the gap held?  What such a row's commit can have touched lies within rec[1] / rec[2]
+        // columns of its first / last base -- as counted at its commit -- plus at most one column per structural event committed
+        // since.  If this row's interval reaches that far, the two no longer commute and the state is not the reference's:
+        // said loudly (never reached with the gaps and the event rates rows jump at; the option "plan_ahead" 0 rules it out).
+        bool bad = false;
+        if (tid > boff && ((hd->jumpmask >> tid) & 1ull)) {
+            const int kkj = hd->next_row + tid;
+            const int kj = jobrows[kkj], Lj = st.rowlen[kj];
+            const long long oj = st.rowoff[kj];
+            const int f = st.rank[st.pos[oj]], l = st.rank[st.pos[oj + Lj - 1]];
+            const int *rec = st.bplan + JR_BASE + 4 * (kkj & 63);
+            const int es = (int)((unsigned)hd->events_total - (unsigned)rec[0]);
+            bad = !(hi + 2 < f - rec[1] - es || l + rec[2] + es < lo - 2);
+        }
+        if (__ballot(bad) != 0ull && tid == 0) atomicCAS(&st.hdr->status, 0, PWR_ERR_ORDER);
+    }
     const int x0 = (int)((long long)L * g / GATHER_G), x1 = (int)((long long)L * (g + 1) / GATHER_G);
     // The marks of the row's own symbols (base + 1 where it has a base, 0 where it has '-', 7 in a blank run between two of
     // its segments): the share clears and sets the columns from its first base up to the next share's first base -- Way[] is
@@ -451,7 +491,7 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
                 long long Lsum = 0;
                 for (int j = 0; j < hd->nb; ++j) {
                     int bo;
-                    const int kj = gather_row_of(hd, j, &bo);
+                    const int kj = gather_row_of(hd, st.bplan, j, &bo);
                     if (kj >= 0) Lsum += st.rowlen[jb.rowids[kj]];
                 }
                 Lsum = max(Lsum, (long long)L);
@@ -3225,6 +3265,10 @@ __device__ void commit_decide(const DState &st, const JobBufs &jb, int njobs, Ba
                 const JobMeta *ms = &metas[skipped[t]];
                 if (!(m->hi + 2 + evabs < ms->lo || ms->hi + 2 + evabs < m->lo)) good = false;
             }
+            // a row that was picked AHEAD of rows that are not in the batch at all (k_commit_finish of the batch before): it commutes
+            // with them as long as the columns this batch has opened or emptied so far cannot have closed the gap it was picked for
+            const bool jumped = st.bplan[0] && j < PLAN_MAX && st.bplan[1 + PLAN_MAX + j] != 0x7fffffff;
+            if (good && jumped && st.bplan[1 + PLAN_MAX + j] <= 2 + evabs) good = false;
             if (!good) {
                 if (why >= 0) p->reasons[why] += 1;
                 if (nskip >= MAXJ) { p->verdict[j] = V_AFTER_STOP; stopped = true; continue; }
@@ -3243,7 +3287,7 @@ __device__ void commit_decide(const DState &st, const JobBufs &jb, int njobs, Ba
                 if (cj->nev > EVCAP) p->big = 1;
             }
             p->live_done += 1;
-            if (nskip > 0) p->ahead_n += 1;
+            if (nskip > 0 || jumped) p->ahead_n += 1;
         } else p->verdict[j] = V_EMPTY;                                           // (a row without bases, PW:1488, is done wherever it stands)
         if (m->off < 64) p->done_mask |= 1ull << m->off; else stopped = true;
     }
@@ -3418,9 +3462,12 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
     __shared__ unsigned sh[COMMIT_NT / 64];
     __shared__ int s_skey[EVCAP], s_scum[EVCAP], s_seg_lo[EVCAP + 1], s_seg_sh[EVCAP + 1], s_seg_pre[EVCAP + 2];
     __shared__ int s_last, s_free, s_w;
+    __shared__ int s_pl[8], s_plo[64], s_phi[64], s_pL[64], s_pgap[64];
+    __shared__ unsigned long long s_ahead, s_okm;
     const int tid = threadIdx.x;
     Hdr *h = st.hdr;
     const BatchPlan *p = jb.plan;
+    if (tid == 0) s_pl[0] = 0;
     const int W = h->W, cur = h->cur;
     const int *order = cur ? st.order1 : st.order0;
     int *norder = cur ? st.order0 : st.order1;
@@ -3576,8 +3623,33 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
                 if (!p->big) h->agree = max(0, min(h->agree, min(p->first, W)));   // the other buffer was left alone
                 else { h->cur = cur ^ 1; h->agree = max(0, min(p->first, W)); }
             }
+            // the rows of this batch that were picked ahead of rows outside it and have committed: what their intervals reach
+            // beyond their bases, for the check of the rows they jumped (k_gather_a)
+            unsigned long long jm = h->jumpmask;
+            if (st.bplan[0]) {
+                for (int j = 0; j < njobs && j < PLAN_MAX; ++j) {
+                    if (p->verdict[j] != V_COMMIT || st.bplan[1 + PLAN_MAX + j] == 0x7fffffff) continue;
+                    const JobMeta *m = &jb.meta[j];
+                    if (m->off >= 64) continue;
+                    const int *nc = jb.newcol + (size_t)j * jb.Lmax;
+                    const int c0 = nc[0], cL = nc[m->L - 1];
+                    int *rec = st.bplan + JR_BASE + 4 * ((h->next_row + m->off) & 63);
+                    rec[0] = (int)(unsigned)(h->events_total + (unsigned long long)p->nev);
+                    rec[1] = ((c0 >> 1) + (c0 & 1)) - m->lo + m->nnew + 4;
+                    rec[2] = m->hi - (cL >> 1) + m->nnew + 4;
+                    jm |= 1ull << m->off;
+                    h->rows_jumped += 1;
+                }
+            }
+            h->events_total += (unsigned long long)p->nev;
+            {
+                int nchg = 0;
+                for (int t = 0; t < p->ncommit; ++t) nchg += jb.cjob[p->cjobs[t]].scanned ? 1 : 0;
+                if (nchg > 0) h->evrate = 0.9f * h->evrate + 0.1f * ((float)p->nev / (float)nchg);
+            }
             const unsigned long long dm = h->ahead | p->done_mask;
             const int adv = ~dm ? __builtin_ctzll(~dm) : 64;
+            h->jumpmask = adv >= 64 ? 0ull : jm >> adv;
             const int done = __builtin_popcountll(p->done_mask);
             h->ncommitted = done;
             h->next_row += adv;
@@ -3600,7 +3672,82 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
                         if (st.rowlen[rowids[k + j]] > l0 + (int)((long long)l0 * h->speclen / 100) + 64) { nb = j; break; }
                 }
                 h->nb = nb;
+                // (what the pick of the next batch's rows below starts from)
+                s_pl[0] = (jb.plan_ahead && h->window > 1 && h->window <= PLAN_MAX && left > 0) ? 1 : 0;
+                s_pl[1] = k; s_pl[2] = h->row_end; s_pl[3] = nb; s_pl[4] = min(h->window, left); s_pl[5] = h->W; s_pl[6] = h->speclen;
+                s_ahead = h->ahead;
+                // rows jump only while the MSA is calm: 64 commits' worth of opened / emptied columns must stay far below the gap
+                // a jump keeps (PLAN_SLACK), and the jumps still pending must not have seen a quarter of it already
+                {
+                    bool calm = h->evrate * 100.0f < (float)jb.plan_evrate_x100;
+                    for (unsigned long long q = h->jumpmask; q && calm; q &= q - 1) {
+                        const int *rec = st.bplan + JR_BASE + 4 * ((k + __builtin_ctzll(q)) & 63);
+                        if ((unsigned)h->events_total - (unsigned)rec[0] > (unsigned)(jb.plan_slack / 4)) calm = false;
+                    }
+                    s_pl[7] = calm ? 1 : 0;
+                }
+                if (!s_pl[0]) st.bplan[0] = 0;                                     // the next rows in order
             }
+        }
+    }
+    __syncthreads();
+    if (s_pl[0]) {
+        // ---- the rows of the NEXT batch.  Its first row is the next one of the k loop; the others are speculation.  Round 3 took
+        // the rows that follow it in order -- which commit only if the rows before them leave their intervals alone, three times
+        // in ten.  But among the next 64 rows there are rows whose band interval is DISJOINT from that of every uncommitted row
+        // before them: they commute with all of those (what "commit ahead" has rested on since round 2), so their
+        // realignment from the present state is exact whatever the rows before them do, and they commit in this very batch.
+        // They are taken first, whatever their length; the slots that are left go to the next rows in order as before.
+        const int k0n = s_pl[1], kend = s_pl[2], Wn = s_pl[5];
+        if (tid < 64) {
+            const int kk = k0n + tid;
+            int lo_ = 0x7fffffff, hi_ = -0x7fffffff, L_ = -1;                       // (not a candidate: committed already, or beyond the slab)
+            if (kk < kend && !((s_ahead >> tid) & 1ull)) {
+                const int kr = rowids[kk];
+                L_ = st.rowlen[kr];
+                if (L_ > 0) {
+                    const long long offr = st.rowoff[kr];
+                    const int w0 = st.rank[st.pos[offr]], wL = st.rank[st.pos[offr + L_ - 1]];
+                    lo_ = max(0, max(0, w0 - st.H) - 1); hi_ = min(Wn - 1, max(0, wL - st.H) + st.B - 1);   // the interval its gather will take
+                }
+            }
+            s_plo[tid] = lo_; s_phi[tid] = hi_; s_pL[tid] = L_;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // distance in columns to the nearest interval of an uncommitted row before it
+            int gap = 0x7fffffff;
+            const int lo_ = s_plo[tid], hi_ = s_phi[tid];
+            for (int i = 0; i < tid; ++i) if (s_pL[i] > 0) gap = min(gap, max(lo_ - s_phi[i], s_plo[i] - hi_));
+            s_pgap[tid] = gap;
+            const unsigned long long okm = __ballot(tid > 0 && s_pL[tid] > 0 && gap > 2 + jb.plan_slack && s_pl[7]);
+            if (tid == 0) s_okm = okm;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int window = s_pl[4], nb_order = s_pl[3];
+            int sel[PLAN_MAX], gp[PLAN_MAX], n = 0;
+            sel[n] = 0; gp[n] = 0x7fffffff; ++n;
+            unsigned long long taken = 1ull;
+            for (int off = 1; off < 64 && n < window; ++off)
+                if ((s_okm >> off) & 1ull) { sel[n] = off; gp[n] = s_pgap[off]; ++n; taken |= 1ull << off; }
+            const int l0 = max(0, s_pL[0]);
+            int inorder = 1;
+            for (int off = 1; off < 64 && n < window && inorder < nb_order; ++off) {
+                if (s_pL[off] < 0) { if (k0n + off >= kend) break; continue; }     // committed ahead already
+                if ((taken >> off) & 1ull) continue;                               // in the batch already: the run of rows goes on behind it
+                if (s_pL[off] > l0 + (int)((long long)l0 * s_pl[6] / 100) + 64) break;   // never a row in order that makes the batch longer than its first
+                sel[n] = off; gp[n] = 0x7fffffff; ++n; ++inorder;
+            }
+            for (int a = 1; a < n; ++a) {                                          // jobs in row order
+                const int so = sel[a], sg = gp[a];
+                int b = a - 1;
+                while (b >= 0 && sel[b] > so) { sel[b + 1] = sel[b]; gp[b + 1] = gp[b]; --b; }
+                sel[b + 1] = so; gp[b + 1] = sg;
+            }
+            for (int j = 0; j < n; ++j) { st.bplan[1 + j] = sel[j]; st.bplan[1 + PLAN_MAX + j] = gp[j]; }
+            st.bplan[0] = 1;
+            h->nb = n;
         }
     }
     if (tid == 0) __threadfence();
@@ -3775,6 +3922,8 @@ struct pwr_ctx {
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
     int seg_budget = 0;                   // > 0: this many for all the jobs of a batch together, dealt by length (measured slower; 0: seg_rows rows each)
     int seg_minrows = 64;                 // ... none with fewer own rows than this
+    int plan_slack = PLAN_SLACK, plan_evrate_x100 = (int)(PLAN_EVRATE_MAX * 100.0f);   // test hooks: the gap a row must keep to be picked ahead, the event rate above which none is
+    int plan_ahead = 1;                   // the speculative rows of a batch: rows among the next 64 whose interval is disjoint from every uncommitted row before them first (0: the next rows in order)
     int seg_balance = 0;                  // 1: ... cut so that every segment runs about as many rows as the others, its warm-up included (measured slower)
     int split_rank = 0, split_world = 1;  // pwr_split_*: this context is replica split_rank of split_world (one per GPU)
     int split_k0 = 0, split_kend = 0;     // ... rows of the slab in progress
@@ -3844,6 +3993,7 @@ extern "C" const char *pwr_strerror(int code)
     case PWR_ERR_INTERNAL: return "inconsistent traceback";
     case PWR_ERR_UNSUPPORTED: return "MSA state is not trimmed ('-' next to a blank or at an edge): pwr_trim_ends first";
     case PWR_ERR_IO: return "cannot open output file";
+    case PWR_ERR_ORDER: return "a row realigned ahead of rows outside its batch no longer commutes with one of them (columns opened or emptied in between closed the gap): rerun with option plan_ahead 0";
     case PWR_ERR_STALL: return "a fill kernel wave waited too long for its neighbour work-group and this geometry has no one-work-group form";
     default: return "unknown error";
     }
@@ -4001,6 +4151,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
     jb.seg_align = c->seg_align;
     jb.seg_budget = c->seg_budget; jb.seg_minrows = c->seg_minrows; jb.seg_balance = c->seg_balance;
+    jb.plan_ahead = c->plan_ahead; jb.plan_slack = c->plan_slack; jb.plan_evrate_x100 = c->plan_evrate_x100;
     jb.rowids = c->d_rowids;
     jb.seg_rows = c->fill_mode == 4 ? c->seg_rows : 0;
     jb.src_start = c->src_start;
@@ -4172,6 +4323,8 @@ static int upload(pwr_ctx *c)
     }
     long long *d_rowoff; int *d_rowlen; uint8_t *d_seq;
     if ((rc = dmalloc(c, &st.hdr, 1))) return rc;
+    if ((rc = dmalloc(c, &st.bplan, BPLAN_WORDS))) return rc;
+    HIPC(hipMemset(st.bplan, 0, sizeof(int) * BPLAN_WORDS));
     if ((rc = dmalloc(c, &d_rowoff, T + 1))) return rc;
     if ((rc = dmalloc(c, &d_rowlen, T))) return rc;
     if ((rc = dmalloc(c, &d_seq, seq.size()))) return rc;
@@ -4380,6 +4533,7 @@ static void stats_from_hdr(pwr_ctx *c, const Hdr &h)
     c->stats.stalls = h.stalls;
     c->stats.rows_ahead = h.rows_ahead;
     c->stats.seg_jobs = h.seg_jobs; c->stats.segs = h.segs; c->stats.seg_fails = h.seg_fails;
+    c->stats.rows_jumped = h.rows_jumped;
     for (int i = 0; i < 4; ++i) c->stats.reject_reason[i] = h.fail_reason[i];
 }
 
@@ -4456,6 +4610,8 @@ static int slab_init(pwr_ctx *c, int k0, int n)
     HIPC(hipMemcpyAsync(&c->st.hdr->speclen, &c->spec_len, sizeof(int), hipMemcpyHostToDevice, c->stream));
     HIPC(hipMemcpyAsync(&c->st.hdr->next_row, &init, sizeof init, hipMemcpyHostToDevice, c->stream));
     HIPC(hipMemsetAsync(&c->st.hdr->ahead, 0, sizeof(unsigned long long), c->stream));
+    HIPC(hipMemsetAsync(c->st.bplan, 0, sizeof(int), c->stream));                 // (the slab's first batch: the next rows in order)
+    HIPC(hipMemsetAsync(&c->st.hdr->jumpmask, 0, sizeof(unsigned long long), c->stream));
     HIPC(hipStreamSynchronize(c->stream));                                     // (init lives on the stack)
     return PWR_OK;
 }
@@ -4817,6 +4973,9 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "seg_align")) { if (c->on_device || (value != 16 && value != 32 && value != 64)) return PWR_ERR_ARG; c->seg_align = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_budget")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->seg_budget = (int)value; c->jb.seg_budget = (int)value; return PWR_OK; }
+    if (!strcmp(key, "plan_slack")) { if (value < 0 || value > 1000000) return PWR_ERR_ARG; c->plan_slack = (int)value; c->jb.plan_slack = (int)value; return PWR_OK; }
+    if (!strcmp(key, "plan_evrate_x100")) { if (value < 0 || value > 100000000) return PWR_ERR_ARG; c->plan_evrate_x100 = (int)value; c->jb.plan_evrate_x100 = (int)value; return PWR_OK; }
+    if (!strcmp(key, "plan_ahead")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->plan_ahead = (int)value; c->jb.plan_ahead = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_balance")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->seg_balance = (int)value; c->jb.seg_balance = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_minrows")) { if (value < 16 || value > 100000) return PWR_ERR_ARG; c->seg_minrows = (int)value; c->jb.seg_minrows = (int)value; return PWR_OK; }
     if (!strcmp(key, "src_start")) { if (c->on_device || value < 0 || value > 1) return PWR_ERR_ARG; c->src_start = (int)value; return PWR_OK; }
@@ -4846,6 +5005,13 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "seg_budget")) *value = c->seg_budget;
     else if (!strcmp(key, "seg_minrows")) *value = c->seg_minrows;
     else if (!strcmp(key, "seg_balance")) *value = c->seg_balance;
+    else if (!strcmp(key, "plan_ahead")) *value = c->plan_ahead;
+    else if (!strcmp(key, "plan_slack")) *value = c->plan_slack;
+    else if (!strcmp(key, "plan_evrate_x100")) *value = c->plan_evrate_x100;
+    else if (!strcmp(key, "evrate_x100")) {                                    // read-only: columns a commit opens / empties, running mean x 100
+        *value = 0;
+        if (c->on_device) { Hdr h; int rc = read_hdr(c, &h); if (rc) return rc; *value = (long)(h.evrate * 100.0f); }
+    }
     else if (!strcmp(key, "warm_pct")) *value = c->warm_pct;
     else if (!strcmp(key, "src_start")) *value = c->src_start;
     else if (!strcmp(key, "warm_adapt")) *value = c->warm_adapt;
@@ -4886,6 +5052,7 @@ extern "C" int pwr_reset_stats(pwr_ctx *c)
         if (hipSetDevice(c->device) != hipSuccess) return PWR_ERR_DEVICE;
         HIPC(hipStreamSynchronize(c->stream));
         HIPC(hipMemset(&c->st.hdr->cells_computed, 0, 16 * sizeof(unsigned long long)));
+        HIPC(hipMemset(&c->st.hdr->rows_jumped, 0, sizeof(unsigned long long)));
     }
     return PWR_OK;
 }

@@ -221,3 +221,73 @@ def test_rows_that_jump_further_than_the_band(bw, opts, oracle):
                        min_aligned=102, seed=30351)
     rows = [bytes(r) for r in dg.build_msa(dg.simulate(cfg))]
     _row_by_row(rows, bw, 3, oracle, window=1, **opts)
+
+
+def test_rows_picked_ahead_commute_and_commit(oracle):
+    """"plan_ahead" (round 4): the speculative rows of a batch are picked by the batch before it -- first the rows among the next
+    64 whose band interval keeps a wide gap from every uncommitted row before them.  They jump rows that are not even in their
+    batch, and the MSA must still be the reference's after every round; with the option off (rows in order, round 3) the result
+    is the same and nothing jumps."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    cfg = dg.SimConfig(kind="Tree", copies=12, coverage=15, difference=0.01, repeat_len=6000, flank=2000,
+                       length_scale=0.12, min_aligned=200, seed=23)
+    rows = [bytes(r) for r in dg.make_msa(cfg)]
+    lib = oracle.lib
+    h = oracle.create(rows, 300)
+    lib.pwo_trim(h)
+    exp = []
+    for rnd in range(3):
+        lib.pwo_realign_round(h)
+        exp.append((lib.pwo_total_score(h), oracle.export(h)))
+    cells = lib.pwo_cells(h)
+    lib.pwo_destroy(h)
+    jumped = {}
+    for plan, window in ((1, 3), (0, 3), (1, 6)):
+        g = PWReAligner(rows, bandwidth=300, window=window, plan_ahead=plan, plan_slack=200)
+        g.trim_ends()
+        for rnd in range(3):
+            g.realign_round()
+            assert g.total_score() == exp[rnd][0], (plan, window, rnd)
+            assert g.export_rows() == exp[rnd][1], (plan, window, rnd)
+        st = g.stats()
+        assert st["cells_reference"] == cells
+        assert st["rows_committed"] == 3 * sum(1 for r in rows if any(c in b"acgtACGT" for c in r))
+        jumped[(plan, window)] = (st["rows_jumped"], st["batches"])
+        g.close()
+    assert jumped[(0, 3)][0] == 0 and jumped[(1, 3)][0] > 0 and jumped[(1, 6)][0] > 0, jumped
+
+
+def test_a_jump_that_does_not_hold_is_reported_not_swallowed(oracle):
+    """The exactness of a jump rests on a gap that columns opened or emptied in between could in principle close; every row that
+    was jumped checks at its gather that it has held (PWR_ERR_ORDER otherwise).  With the safety margins taken away (gap 0, no
+    limit on the event rate) on MSAs whose columns open and empty by the dozen, a run either ends with that error or with the
+    reference's MSA -- never with another MSA and no error."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner, PwrError
+    lib = oracle.lib
+    outcomes = {"exact": 0, "reported": 0}
+    jumps = 0
+    for seed in range(8):
+        cfg = dg.SimConfig(kind="Distributed", copies=3, coverage=3, difference=0.03, repeat_len=2500, flank=600,
+                           length_scale=0.02, min_aligned=40, seed=100 + seed)
+        rows = [bytes(r) for r in dg.build_msa(dg.simulate(cfg))]
+        bw = (6, 10, 16, 24)[seed % 4]
+        g = PWReAligner(rows, bandwidth=bw, window=(4, 8)[seed % 2], plan_slack=0, plan_evrate_x100=100000000)
+        g.trim_ends()
+        h = oracle.create(rows, bw)
+        lib.pwo_trim(h)
+        try:
+            for rnd in range(3):
+                g.realign_round()
+                lib.pwo_realign_round(h)
+                assert g.total_score() == lib.pwo_total_score(h), (seed, rnd)
+                assert g.export_rows() == oracle.export(h), (seed, rnd)
+            outcomes["exact"] += 1
+            jumps += g.stats()["rows_jumped"]
+        except PwrError as e:
+            assert e.code == -10, e                                  # PWR_ERR_ORDER: said loudly
+            outcomes["reported"] += 1
+        lib.pwo_destroy(h)
+        g.close()
+    assert outcomes["exact"] + outcomes["reported"] == 8 and (jumps > 0 or outcomes["reported"] > 0), (outcomes, jumps)
