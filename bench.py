@@ -79,6 +79,14 @@ def cpu_baseline(rows, bandwidth, budget_s=15.0):
                       f"oracle/pw_oracle.c -O2, array-based restatement pinned to the reference by tests/golden)"}
 
 
+def opt_or_none(ctx, key):
+    """an option's value, None for a library that does not know it (scripts/dev/ab.sh runs older builds)"""
+    try:
+        return ctx.get_option(key)
+    except Exception:
+        return None
+
+
 def slab_bounds(T, slabs, i):
     """Rows [k0, k1) of step i: slab i mod slabs of round i // slabs."""
     s = i % slabs
@@ -312,7 +320,7 @@ def main():
                        "useful_frac": (st["cells_reference"] / st["cells_computed"]) if st["cells_computed"] else None,
                        "commits_per_batch": (st["rows_committed"] / st["batches"]) if st["batches"] else None,
                        "seg_jobs": st["seg_jobs"], "segs": st["segs"], "seg_fails": st["seg_fails"],
-                       "options": {k_: ctxs[0].get_option(k_) for k_ in ("window", "fill", "waves", "spec_len", "seg_rows", "seg_max", "warm_pct", "src_start", "warm_adapt", "warm_min_pct", "warm_down_pm", "warm_up_pm", "warm_now", "plan_ahead", "plan_slack", "plan_evrate_x100", "evrate_x100")} if ctxs else None,
+                       "options": {k_: opt_or_none(ctxs[0], k_) for k_ in ("window", "fill", "waves", "spec_len", "seg_rows", "seg_max", "warm_pct", "src_start", "warm_adapt", "warm_min_pct", "warm_down_pm", "warm_up_pm", "warm_now", "plan_ahead", "plan_slack", "plan_evrate_x100", "evrate_x100")} if ctxs else None,
                        "generate_s": round(gen_s, 1), "input": args.input, "initial_aligner": ia_info, "complete": bool(final)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

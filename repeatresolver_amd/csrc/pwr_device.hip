@@ -133,6 +133,7 @@ struct DState {
 #define JR_BASE (1 + 2 * PLAN_MAX)  // behind the plan: one record per row that jumped, at (row index & 63): {events_total at its commit,
                                     // columns of its interval left of its first base, right of its last base (own new columns included), -}
 #define BPLAN_WORDS (JR_BASE + 64 * 4)
+#define PLAN_CAND 128               // rows k_commit_finish looks up beside its header work (the row pointer moves by at most 64)
 #define PLAN_EVRATE_MAX 12.0f       // rows jump only while a commit opens / empties fewer columns than this on average
 #define PLAN_SLACK 2048               // a row is picked ahead only if its interval keeps this many columns (+ 2) from every row it jumps
 
@@ -3437,21 +3438,6 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_apply(DState st, JobBufs j
     for (int i = gt; i < total; i += GT) { const int sgi = seg_of(i); tmp[i] = order[ev.seg_lo[sgi] + (i - ev.seg_pre[sgi])]; }
 }
 
-// The header as it stands after a batch goes to pinned host memory straight from the commit: every word but the sequence
-// number, a system-scope fence, then the number -- the host polls that word, no copy command and no event record (6 us each
-// on the stream) behind every batch.
-__device__ __forceinline__ void publish_header(const Hdr *h, Hdr *host_copy, unsigned seq)
-{
-    if (!host_copy) return;
-    constexpr int NWORDS = (int)(sizeof(Hdr) / 4), SEQW = (int)(offsetof(Hdr, seq) / 4);
-    if ((int)threadIdx.x < NWORDS && (int)threadIdx.x != SEQW) {
-        reinterpret_cast<volatile int *>(host_copy)[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const int *>(h) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence_system();                                                    // (by the waves that wrote)
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { *reinterpret_cast<volatile unsigned *>(&host_copy->seq) = seq; __threadfence_system(); }
-}
-
 // Second half of the renumbering, then -- by the work-group that arrives last, when every other one has finished -- the header:
 // the width, the k loop's row pointer (PW:1695 lives on the device), the size of the next batch.  A batch costs as long as its
 // longest fill, and rows that overlap the rows before them are almost always invalidated while the MSA is still moving, so
@@ -3463,7 +3449,11 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
     __shared__ int s_skey[EVCAP], s_scum[EVCAP], s_seg_lo[EVCAP + 1], s_seg_sh[EVCAP + 1], s_seg_pre[EVCAP + 2];
     __shared__ int s_last, s_free, s_w;
     __shared__ int s_pl[8], s_plo[64], s_phi[64], s_pL[64], s_pgap[64];
-    __shared__ unsigned long long s_ahead, s_okm;
+    __shared__ unsigned long long s_ahead, s_okm, s_jm;
+    __shared__ unsigned s_ev;
+    __shared__ int s_bp[JR_BASE], s_sel[PLAN_MAX + 1], s_gp[PLAN_MAX + 1];
+    __shared__ __attribute__((aligned(16))) int s_hw[(sizeof(Hdr) + 3) / 4];
+    __shared__ int s_cw0[PLAN_CAND], s_cwL[PLAN_CAND], s_cL[PLAN_CAND], s_oldnext, s_rowend;
     const int tid = threadIdx.x;
     Hdr *h = st.hdr;
     const BatchPlan *p = jb.plan;
@@ -3580,112 +3570,129 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
     }
     __syncthreads();
     if (!s_last) return;
+    // The header is worked on in LDS: fetched by all threads at once, changed by lane 0 (a walk through a dozen cache lines of
+    // global memory, one dependent round trip each, was half of this kernel), written back and sent to the host by all.
+    constexpr int HW = (int)(sizeof(Hdr) / 4);
+    static_assert(HW <= COMMIT_NT, "one word of the header per thread");
+    if (tid < HW) s_hw[tid] = reinterpret_cast<const int *>(h)[tid];
+    if (tid < JR_BASE) s_bp[tid] = st.bplan[tid];                                  // (this batch's plan, for the lane that writes the header)
+    __syncthreads();
+    Hdr *const hh = reinterpret_cast<Hdr *>(s_hw);
+    if (tid == 0) { s_oldnext = hh->next_row; s_rowend = hh->row_end; }
+    __syncthreads();
+    if (tid >= 64 && tid < 64 + PLAN_CAND) {
+        // While lane 0 writes the header: the rows the NEXT batch may pick from, one lane each -- the 128 rows from the row
+        // pointer as it stood (it moves on by at most 64): the columns of their end bases as the state is now, final for
+        // this batch, and their lengths.  (These loads are four dependent round trips; beside the header's they cost nothing.)
+        const int c_ = tid - 64, kk = s_oldnext + c_;
+        int w0 = 0, wL = 0, L_ = -1;
+        if (kk < s_rowend) {
+            const int kr = rowids[kk];
+            L_ = st.rowlen[kr];
+            if (L_ > 0) { const long long offr = st.rowoff[kr]; w0 = st.rank[st.pos[offr]]; wL = st.rank[st.pos[offr + L_ - 1]]; }
+        }
+        s_cw0[c_] = w0; s_cwL[c_] = wL; s_cL[c_] = L_;
+    }
     if (tid == 0) {
         *jb.ticket = 0u;
-        h->ncommitted = 0; h->stop = 0;
+        hh->ncommitted = 0; hh->stop = 0;
         if (!p->idle) {
-            int version = h->version;
+            int version = hh->version;
             for (int j = 0; j < njobs && j < MAXJ; ++j) {
                 const int v = p->verdict[j];
                 if (v == V_NONE) break;
                 JobMeta *m = &jb.meta[j];
-                if (v == V_STOP_GROW) h->need_grow = 1;
+                if (v == V_STOP_GROW) hh->need_grow = 1;
                 else if (v == V_STOP_ABORT) {
                     // k_fill_v3 gave this job up (time-out): it is realigned again, by k_fill_v2, as are the next batches
-                    h->stalls += 1;
-                    if (jb.wpNW <= 16) h->fallback = 65; else atomicCAS(&h->status, 0, PWR_ERR_STALL);   // (no one-work-group form of 17 waves)
+                    hh->stalls += 1;
+                    if (jb.wpNW <= 16) hh->fallback = 65; else atomicCAS(&hh->status, 0, PWR_ERR_STALL);   // (no one-work-group form of 17 waves)
                 } else if (v == V_STOP_SEGFAIL) {
                     // a segment of its fill had not forgotten its start when its own rows began (k_seg_check): the row is
                     // realigned again, with the longest warm-up, then in one piece
-                    h->seg_fails += 1; h->noseg_level = h->noseg_row == m->k ? h->noseg_level + 1 : 1; h->noseg_row = m->k;
-                    if (h->noseg_level == 1 && h->warm_step > 0) h->warm_cur = min(h->warm_hi, h->warm_cur + h->warm_up);
-                } else if (v == V_STALE) h->stop = 1;
+                    hh->seg_fails += 1; hh->noseg_level = hh->noseg_row == m->k ? hh->noseg_level + 1 : 1; hh->noseg_row = m->k;
+                    if (hh->noseg_level == 1 && hh->warm_step > 0) hh->warm_cur = min(hh->warm_hi, hh->warm_cur + hh->warm_up);
+                } else if (v == V_STALE) hh->stop = 1;
                 else if (v == V_COMMIT) {
                     const CommitJob *cj = &jb.cjob[j];
                     if (cj->scanned) {
                         version += 1;
-                        if (cj->nchg > 0 || m->nnew > 0) h->rows_changed += 1;
+                        if (cj->nchg > 0 || m->nnew > 0) hh->rows_changed += 1;
                         if (st.nbrk[m->k]) st.nbrk[m->k] = 0;
                     }
-                    h->cells_reference += m->cells;
-                    if (h->noseg_row == m->k) { h->noseg_row = -1; h->noseg_level = 0; }
-                    else if (m->nseg > 1) h->warm_cur = max(h->warm_lo, h->warm_cur - h->warm_step);
-                    if (m->wide) h->rows_wide += 1;
+                    hh->cells_reference += m->cells;
+                    if (hh->noseg_row == m->k) { hh->noseg_row = -1; hh->noseg_level = 0; }
+                    else if (m->nseg > 1) hh->warm_cur = max(hh->warm_lo, hh->warm_cur - hh->warm_step);
+                    if (m->wide) hh->rows_wide += 1;
                 }
             }
-            h->version = version;
-            for (int i = 0; i < 4; ++i) h->fail_reason[i] += (unsigned long long)p->reasons[i];
+            hh->version = version;
+            for (int i = 0; i < 4; ++i) hh->fail_reason[i] += (unsigned long long)p->reasons[i];
             if (p->restructure) {
                 const int cum = jb.sev->cum;
-                h->W = W + cum;
-                h->nslots = nslots + (p->nnew - take);
-                h->nfree = nfree - take + p->ndel;
-                if (!p->big) h->agree = max(0, min(h->agree, min(p->first, W)));   // the other buffer was left alone
-                else { h->cur = cur ^ 1; h->agree = max(0, min(p->first, W)); }
+                hh->W = W + cum;
+                hh->nslots = nslots + (p->nnew - take);
+                hh->nfree = nfree - take + p->ndel;
+                if (!p->big) hh->agree = max(0, min(hh->agree, min(p->first, W)));   // the other buffer was left alone
+                else { hh->cur = cur ^ 1; hh->agree = max(0, min(p->first, W)); }
             }
             // the rows of this batch that were picked ahead of rows outside it and have committed: what their intervals reach
             // beyond their bases, for the check of the rows they jumped (k_gather_a)
-            unsigned long long jm = h->jumpmask;
-            if (st.bplan[0]) {
+            unsigned long long jm = hh->jumpmask;
+            if (s_bp[0]) {
                 for (int j = 0; j < njobs && j < PLAN_MAX; ++j) {
-                    if (p->verdict[j] != V_COMMIT || st.bplan[1 + PLAN_MAX + j] == 0x7fffffff) continue;
+                    if (p->verdict[j] != V_COMMIT || s_bp[1 + PLAN_MAX + j] == 0x7fffffff) continue;
                     const JobMeta *m = &jb.meta[j];
                     if (m->off >= 64) continue;
                     const int *nc = jb.newcol + (size_t)j * jb.Lmax;
                     const int c0 = nc[0], cL = nc[m->L - 1];
-                    int *rec = st.bplan + JR_BASE + 4 * ((h->next_row + m->off) & 63);
-                    rec[0] = (int)(unsigned)(h->events_total + (unsigned long long)p->nev);
+                    int *rec = st.bplan + JR_BASE + 4 * ((hh->next_row + m->off) & 63);
+                    rec[0] = (int)(unsigned)(hh->events_total + (unsigned long long)p->nev);
                     rec[1] = ((c0 >> 1) + (c0 & 1)) - m->lo + m->nnew + 4;
                     rec[2] = m->hi - (cL >> 1) + m->nnew + 4;
                     jm |= 1ull << m->off;
-                    h->rows_jumped += 1;
+                    hh->rows_jumped += 1;
                 }
             }
-            h->events_total += (unsigned long long)p->nev;
+            hh->events_total += (unsigned long long)p->nev;
             {
                 int nchg = 0;
                 for (int t = 0; t < p->ncommit; ++t) nchg += jb.cjob[p->cjobs[t]].scanned ? 1 : 0;
-                if (nchg > 0) h->evrate = 0.9f * h->evrate + 0.1f * ((float)p->nev / (float)nchg);
+                if (nchg > 0) hh->evrate = 0.9f * hh->evrate + 0.1f * ((float)p->nev / (float)nchg);
             }
-            const unsigned long long dm = h->ahead | p->done_mask;
+            const unsigned long long dm = hh->ahead | p->done_mask;
             const int adv = ~dm ? __builtin_ctzll(~dm) : 64;
-            h->jumpmask = adv >= 64 ? 0ull : jm >> adv;
+            hh->jumpmask = adv >= 64 ? 0ull : jm >> adv;
             const int done = __builtin_popcountll(p->done_mask);
-            h->ncommitted = done;
-            h->next_row += adv;
-            h->ahead = adv >= 64 ? 0ull : dm >> adv;
-            h->rows_ahead += (unsigned long long)p->ahead_n;
-            if (h->fallback > 0 && jb.v2_follows) h->fallback -= 1;
-            if (h->need64 > 0 && jb.f64_follows) h->need64 -= 1;
-            if (p->live_all > 0) h->batches += 1;
-            h->rows_committed += (unsigned long long)p->live_done;
-            h->rows_recomputed += (unsigned long long)(p->live_all - p->live_done);
-            if (h->status == 0 && !h->need_grow && done > 0) {
-                const float ema = 0.75f * h->ema + 0.25f * (float)done;
-                h->ema = ema;
-                const int k = h->next_row, left = h->row_end - k;
+            hh->ncommitted = done;
+            hh->next_row += adv;
+            hh->ahead = adv >= 64 ? 0ull : dm >> adv;
+            hh->rows_ahead += (unsigned long long)p->ahead_n;
+            if (hh->fallback > 0 && jb.v2_follows) hh->fallback -= 1;
+            if (hh->need64 > 0 && jb.f64_follows) hh->need64 -= 1;
+            if (p->live_all > 0) hh->batches += 1;
+            hh->rows_committed += (unsigned long long)p->live_done;
+            hh->rows_recomputed += (unsigned long long)(p->live_all - p->live_done);
+            if (hh->status == 0 && !hh->need_grow && done > 0) {
+                const float ema = 0.75f * hh->ema + 0.25f * (float)done;
+                hh->ema = ema;
+                const int k = hh->next_row, left = hh->row_end - k;
                 int nb = (int)(ema + 2.6f);
-                nb = max(1, min(nb, min(h->window, left)));
+                nb = max(1, min(nb, min(hh->window, left)));
                 if (left > 0) {
                     const int l0 = st.rowlen[rowids[k]];
                     for (int j = 1; j < nb; ++j)
-                        if (st.rowlen[rowids[k + j]] > l0 + (int)((long long)l0 * h->speclen / 100) + 64) { nb = j; break; }
+                        if (st.rowlen[rowids[k + j]] > l0 + (int)((long long)l0 * hh->speclen / 100) + 64) { nb = j; break; }
                 }
-                h->nb = nb;
+                hh->nb = nb;
                 // (what the pick of the next batch's rows below starts from)
-                s_pl[0] = (jb.plan_ahead && h->window > 1 && h->window <= PLAN_MAX && left > 0) ? 1 : 0;
-                s_pl[1] = k; s_pl[2] = h->row_end; s_pl[3] = nb; s_pl[4] = min(h->window, left); s_pl[5] = h->W; s_pl[6] = h->speclen;
-                s_ahead = h->ahead;
+                s_pl[0] = (jb.plan_ahead && hh->window > 1 && hh->window <= PLAN_MAX && left > 0) ? 1 : 0;
+                s_pl[1] = k; s_pl[2] = hh->row_end; s_pl[3] = nb; s_pl[4] = min(hh->window, left); s_pl[5] = hh->W; s_pl[6] = hh->speclen;
+                s_ahead = hh->ahead;
                 // rows jump only while the MSA is calm: 64 commits' worth of opened / emptied columns must stay far below the gap
-                // a jump keeps (PLAN_SLACK), and the jumps still pending must not have seen a quarter of it already
-                {
-                    bool calm = h->evrate * 100.0f < (float)jb.plan_evrate_x100;
-                    for (unsigned long long q = h->jumpmask; q && calm; q &= q - 1) {
-                        const int *rec = st.bplan + JR_BASE + 4 * ((k + __builtin_ctzll(q)) & 63);
-                        if ((unsigned)h->events_total - (unsigned)rec[0] > (unsigned)(jb.plan_slack / 4)) calm = false;
-                    }
-                    s_pl[7] = calm ? 1 : 0;
-                }
+                // a jump keeps, and the jumps still pending must not have seen a quarter of it already (looked up by the lanes below)
+                s_pl[7] = hh->evrate * 100.0f < (float)jb.plan_evrate_x100 ? 1 : 0;
+                s_jm = hh->jumpmask; s_ev = (unsigned)hh->events_total;
                 if (!s_pl[0]) st.bplan[0] = 0;                                     // the next rows in order
             }
         }
@@ -3700,16 +3707,11 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
         // They are taken first, whatever their length; the slots that are left go to the next rows in order as before.
         const int k0n = s_pl[1], kend = s_pl[2], Wn = s_pl[5];
         if (tid < 64) {
-            const int kk = k0n + tid;
+            const int kk = k0n + tid, c_ = kk - s_oldnext;                          // (its place among the rows looked up above)
             int lo_ = 0x7fffffff, hi_ = -0x7fffffff, L_ = -1;                       // (not a candidate: committed already, or beyond the slab)
-            if (kk < kend && !((s_ahead >> tid) & 1ull)) {
-                const int kr = rowids[kk];
-                L_ = st.rowlen[kr];
-                if (L_ > 0) {
-                    const long long offr = st.rowoff[kr];
-                    const int w0 = st.rank[st.pos[offr]], wL = st.rank[st.pos[offr + L_ - 1]];
-                    lo_ = max(0, max(0, w0 - st.H) - 1); hi_ = min(Wn - 1, max(0, wL - st.H) + st.B - 1);   // the interval its gather will take
-                }
+            if (kk < kend && c_ < PLAN_CAND && !((s_ahead >> tid) & 1ull)) {
+                L_ = s_cL[c_];
+                if (L_ > 0) { lo_ = max(0, max(0, s_cw0[c_] - st.H) - 1); hi_ = min(Wn - 1, max(0, s_cwL[c_] - st.H) + st.B - 1); }   // the interval its gather will take
             }
             s_plo[tid] = lo_; s_phi[tid] = hi_; s_pL[tid] = L_;
         }
@@ -3720,39 +3722,51 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
             const int lo_ = s_plo[tid], hi_ = s_phi[tid];
             for (int i = 0; i < tid; ++i) if (s_pL[i] > 0) gap = min(gap, max(lo_ - s_phi[i], s_plo[i] - hi_));
             s_pgap[tid] = gap;
-            const unsigned long long okm = __ballot(tid > 0 && s_pL[tid] > 0 && gap > 2 + jb.plan_slack && s_pl[7]);
+            bool spent = false;                                                    // a pending jump that has seen too many events already
+            if ((s_jm >> tid) & 1ull) spent = s_ev - (unsigned)st.bplan[JR_BASE + 4 * ((k0n + tid) & 63)] > (unsigned)(jb.plan_slack / 4);
+            const bool calm = s_pl[7] != 0 && __ballot(spent) == 0ull;
+            const unsigned long long okm = __ballot(tid > 0 && s_pL[tid] > 0 && gap > 2 + jb.plan_slack && calm);
             if (tid == 0) s_okm = okm;
         }
         __syncthreads();
         if (tid == 0) {
             const int window = s_pl[4], nb_order = s_pl[3];
-            int sel[PLAN_MAX], gp[PLAN_MAX], n = 0;
-            sel[n] = 0; gp[n] = 0x7fffffff; ++n;
+            int n = 0;
+            s_sel[n] = 0; s_gp[n] = 0x7fffffff; ++n;
             unsigned long long taken = 1ull;
-            for (int off = 1; off < 64 && n < window; ++off)
-                if ((s_okm >> off) & 1ull) { sel[n] = off; gp[n] = s_pgap[off]; ++n; taken |= 1ull << off; }
+            for (unsigned long long q = s_okm & ~1ull; q && n < window; q &= q - 1) {
+                const int off = __builtin_ctzll(q);
+                s_sel[n] = off; s_gp[n] = s_pgap[off]; ++n; taken |= 1ull << off;
+            }
             const int l0 = max(0, s_pL[0]);
             int inorder = 1;
             for (int off = 1; off < 64 && n < window && inorder < nb_order; ++off) {
                 if (s_pL[off] < 0) { if (k0n + off >= kend) break; continue; }     // committed ahead already
                 if ((taken >> off) & 1ull) continue;                               // in the batch already: the run of rows goes on behind it
                 if (s_pL[off] > l0 + (int)((long long)l0 * s_pl[6] / 100) + 64) break;   // never a row in order that makes the batch longer than its first
-                sel[n] = off; gp[n] = 0x7fffffff; ++n; ++inorder;
+                s_sel[n] = off; s_gp[n] = 0x7fffffff; ++n; ++inorder;
             }
             for (int a = 1; a < n; ++a) {                                          // jobs in row order
-                const int so = sel[a], sg = gp[a];
+                const int so = s_sel[a], sg = s_gp[a];
                 int b = a - 1;
-                while (b >= 0 && sel[b] > so) { sel[b + 1] = sel[b]; gp[b + 1] = gp[b]; --b; }
-                sel[b + 1] = so; gp[b + 1] = sg;
+                while (b >= 0 && s_sel[b] > so) { s_sel[b + 1] = s_sel[b]; s_gp[b + 1] = s_gp[b]; --b; }
+                s_sel[b + 1] = so; s_gp[b + 1] = sg;
             }
-            for (int j = 0; j < n; ++j) { st.bplan[1 + j] = sel[j]; st.bplan[1 + PLAN_MAX + j] = gp[j]; }
+            for (int j = 0; j < n; ++j) { st.bplan[1 + j] = s_sel[j]; st.bplan[1 + PLAN_MAX + j] = s_gp[j]; }
             st.bplan[0] = 1;
-            h->nb = n;
+            hh->nb = n;
         }
     }
-    if (tid == 0) __threadfence();
     __syncthreads();
-    publish_header(h, host_copy, host_seq);
+    // back to global memory, and the copy for the host: every word but the sequence number, a system-scope fence by the waves that
+    // wrote, then the number -- the host polls that word, no copy command and no event record (6 us each on the stream) per batch
+    if (tid < HW) reinterpret_cast<int *>(h)[tid] = s_hw[tid];
+    if (host_copy) {
+        constexpr int SEQW = (int)(offsetof(Hdr, seq) / 4);
+        if (tid < HW && tid != SEQW) { reinterpret_cast<volatile int *>(host_copy)[tid] = s_hw[tid]; __threadfence_system(); }
+        __syncthreads();
+        if (tid == 0) { *reinterpret_cast<volatile unsigned *>(&host_copy->seq) = host_seq; __threadfence_system(); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
