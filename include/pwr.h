@@ -152,6 +152,9 @@ void pwr_snapshot_free(pwr_snapshot *snap);
  *               all of those, so they commit in this very batch), then the next rows in order as before; rows are picked ahead only
  *               while a commit opens / empties fewer than 12 columns on average, and every row that was jumped checks at its gather
  *               that the gap has held (PWR_ERR_ORDER otherwise); 0: the next rows in order (round 3).  "window" above 16: in order.
+ *   "fail_stops"
+ *               0 (default): a row whose segment check failed waits for its repeat like a stale row -- later rows of the batch whose
+ *               band intervals are disjoint from its own may commit ahead of it; 1: its batch ends with it (rounds 3's rule)
  *   "seg_balance"
  *               1: the own parts of a job's segments are cut so that every segment runs about the same number of rows, its warm-up
  *               included (the first has none; a warm-up of so many columns is more rows where the bases sit closer); default 0 =

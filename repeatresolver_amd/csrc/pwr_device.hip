@@ -184,6 +184,7 @@ struct JobBufs {
     int seg_budget, seg_minrows;   // segments all jobs of a batch may have together (dealt by length), none with fewer own rows than seg_minrows
     int seg_balance;               // 1: the own parts are cut so that all segments of a job run about the same number of rows, warm-up included
     int plan_ahead;                // 1: the rows of a batch are picked by the batch before it: rows that commute with every row before them first
+    int fail_stops;                     // 1: a job that failed its segment check ends its batch (test hook; 0: later rows that commute with it may still commit)
     int plan_slack, plan_evrate_x100;   // ... which keep more than this many columns from them; only while a commit opens / empties fewer columns than this / 100 on average
     const int *rowids;             // the slab's rows (the plan of a job looks at the lengths of the batch's other jobs)
     int gstride;                   // rows per wave of a job's mailbox area
@@ -3238,7 +3239,13 @@ __device__ void commit_decide(const DState &st, const JobBufs &jb, int njobs, Ba
             if ((long long)W + p->nnew + m->L + 64 > st.colcap || (long long)h->nslots + p->nnew + m->L + 64 > st.slotcap) { p->verdict[j] = V_STOP_GROW; stopped = true; continue; }
             if (m->wide && !jb.f64_follows) { p->verdict[j] = V_STOP_WIDE; stopped = true; continue; }   // (its batch came without k_fill64: the next ones bring it)
             if (m->abort) { p->verdict[j] = V_STOP_ABORT; stopped = true; continue; }
-            if (m->segfail) { p->verdict[j] = V_STOP_SEGFAIL; stopped = true; continue; }
+            if (m->segfail) {
+                // its fill is repeated with a longer warm-up in the next batch: until then it is a row like a stale one, and a
+                // later row that commutes with it may commit ahead of it (`fail_stops`: the batch ends here, as up to round 3)
+                p->verdict[j] = V_STOP_SEGFAIL;
+                if (jb.fail_stops || nskip >= MAXJ) stopped = true; else skipped[nskip++] = j;
+                continue;
+            }
             bool good = true;
             int why = -1;
             int d = 0, r = 0;                                                     // columns the jobs committed before open (net) left / right of this job's interval
@@ -3597,7 +3604,7 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
         *jb.ticket = 0u;
         hh->ncommitted = 0; hh->stop = 0;
         if (!p->idle) {
-            int version = hh->version;
+            int version = hh->version, nfail = 0;
             for (int j = 0; j < njobs && j < MAXJ; ++j) {
                 const int v = p->verdict[j];
                 if (v == V_NONE) break;
@@ -3610,8 +3617,13 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
                 } else if (v == V_STOP_SEGFAIL) {
                     // a segment of its fill had not forgotten its start when its own rows began (k_seg_check): the row is
                     // realigned again, with the longest warm-up, then in one piece
-                    hh->seg_fails += 1; hh->noseg_level = hh->noseg_row == m->k ? hh->noseg_level + 1 : 1; hh->noseg_row = m->k;
-                    if (hh->noseg_level == 1 && hh->warm_step > 0) hh->warm_cur = min(hh->warm_hi, hh->warm_cur + hh->warm_up);
+                    // (only the FIRST such row of a batch is tracked: it is the one the next batches begin with until it has
+                    // passed, so the escalation to one piece always terminates; another one is simply repeated when its turn comes)
+                    hh->seg_fails += 1;
+                    if (!nfail++) {
+                        hh->noseg_level = hh->noseg_row == m->k ? hh->noseg_level + 1 : 1; hh->noseg_row = m->k;
+                        if (hh->noseg_level == 1 && hh->warm_step > 0) hh->warm_cur = min(hh->warm_hi, hh->warm_cur + hh->warm_up);
+                    } else if (hh->warm_step > 0) hh->warm_cur = min(hh->warm_hi, hh->warm_cur + hh->warm_up);
                 } else if (v == V_STALE) hh->stop = 1;
                 else if (v == V_COMMIT) {
                     const CommitJob *cj = &jb.cjob[j];
@@ -3936,6 +3948,7 @@ struct pwr_ctx {
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
     int seg_budget = 0;                   // > 0: this many for all the jobs of a batch together, dealt by length (measured slower; 0: seg_rows rows each)
     int seg_minrows = 64;                 // ... none with fewer own rows than this
+    int fail_stops = 0;
     int plan_slack = PLAN_SLACK, plan_evrate_x100 = (int)(PLAN_EVRATE_MAX * 100.0f);   // test hooks: the gap a row must keep to be picked ahead, the event rate above which none is
     int plan_ahead = 1;                   // the speculative rows of a batch: rows among the next 64 whose interval is disjoint from every uncommitted row before them first (0: the next rows in order)
     int seg_balance = 0;                  // 1: ... cut so that every segment runs about as many rows as the others, its warm-up included (measured slower)
@@ -4165,6 +4178,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
     jb.seg_align = c->seg_align;
     jb.seg_budget = c->seg_budget; jb.seg_minrows = c->seg_minrows; jb.seg_balance = c->seg_balance;
+    jb.fail_stops = c->fail_stops;
     jb.plan_ahead = c->plan_ahead; jb.plan_slack = c->plan_slack; jb.plan_evrate_x100 = c->plan_evrate_x100;
     jb.rowids = c->d_rowids;
     jb.seg_rows = c->fill_mode == 4 ? c->seg_rows : 0;
@@ -4988,6 +5002,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_budget")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->seg_budget = (int)value; c->jb.seg_budget = (int)value; return PWR_OK; }
     if (!strcmp(key, "plan_slack")) { if (value < 0 || value > 1000000) return PWR_ERR_ARG; c->plan_slack = (int)value; c->jb.plan_slack = (int)value; return PWR_OK; }
+    if (!strcmp(key, "fail_stops")) { if (value < 0 || value > 1) return PWR_ERR_ARG; c->fail_stops = (int)value; c->jb.fail_stops = (int)value; return PWR_OK; }
     if (!strcmp(key, "plan_evrate_x100")) { if (value < 0 || value > 100000000) return PWR_ERR_ARG; c->plan_evrate_x100 = (int)value; c->jb.plan_evrate_x100 = (int)value; return PWR_OK; }
     if (!strcmp(key, "plan_ahead")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->plan_ahead = (int)value; c->jb.plan_ahead = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_balance")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->seg_balance = (int)value; c->jb.seg_balance = (int)value; return PWR_OK; }
@@ -5022,6 +5037,7 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "plan_ahead")) *value = c->plan_ahead;
     else if (!strcmp(key, "plan_slack")) *value = c->plan_slack;
     else if (!strcmp(key, "plan_evrate_x100")) *value = c->plan_evrate_x100;
+    else if (!strcmp(key, "fail_stops")) *value = c->fail_stops;
     else if (!strcmp(key, "evrate_x100")) {                                    // read-only: columns a commit opens / empties, running mean x 100
         *value = 0;
         if (c->on_device) { Hdr h; int rc = read_hdr(c, &h); if (rc) return rc; *value = (long)(h.evrate * 100.0f); }

@@ -258,6 +258,42 @@ def test_rows_picked_ahead_commute_and_commit(oracle):
     assert jumped[(0, 3)][0] == 0 and jumped[(1, 3)][0] > 0 and jumped[(1, 6)][0] > 0, jumped
 
 
+def test_rows_commit_past_a_row_whose_check_failed(oracle):
+    """A job whose segment check failed is repeated in the next batch; until then it is an uncommitted row like a stale one,
+    and a later row of the batch that commutes with it may commit ahead of it (round 4; `fail_stops` 1: the batch ends at
+    the failed job, as before).  Far too short a warm-up makes many checks fail: same MSA as the reference's after every
+    round either way, fewer batches with the rows that go past."""
+    from repeatresolver_amd import datagen as dg
+    from repeatresolver_amd.realigner import PWReAligner
+    cfg = dg.SimConfig(kind="Tree", copies=12, coverage=15, difference=0.01, repeat_len=6000, flank=2000,
+                       length_scale=0.12, min_aligned=200, seed=29)
+    rows = [bytes(r) for r in dg.make_msa(cfg)]
+    lib = oracle.lib
+    h = oracle.create(rows, 300)
+    lib.pwo_trim(h)
+    exp = []
+    for rnd in range(2):
+        lib.pwo_realign_round(h)
+        exp.append((lib.pwo_total_score(h), oracle.export(h)))
+    cells = lib.pwo_cells(h)
+    lib.pwo_destroy(h)
+    seen = {}
+    for stops, plan in ((1, 0), (0, 0), (0, 1)):
+        g = PWReAligner(rows, bandwidth=300, window=6, seg_rows=64, seg_max=64, warm_pct=25, warm_adapt=0, plan_ahead=plan,
+                        plan_slack=200, fail_stops=stops)
+        g.trim_ends()
+        for rnd in range(2):
+            g.realign_round()
+            assert g.total_score() == exp[rnd][0], (stops, plan, rnd)
+            assert g.export_rows() == exp[rnd][1], (stops, plan, rnd)
+        st = g.stats()
+        assert st["cells_reference"] == cells
+        assert st["seg_fails"] > 0, st
+        seen[(stops, plan)] = (st["batches"], st["rows_ahead"], st["seg_fails"])
+        g.close()
+    assert seen[(0, 0)][0] < seen[(1, 0)][0] and seen[(0, 0)][1] > seen[(1, 0)][1], seen
+
+
 def test_a_jump_that_does_not_hold_is_reported_not_swallowed(oracle):
     """The exactness of a jump rests on a gap that columns opened or emptied in between could in principle close; every row that
     was jumped checks at its gather that it has held (PWR_ERR_ORDER otherwise).  With the safety margins taken away (gap 0, no
