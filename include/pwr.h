@@ -152,6 +152,12 @@ void pwr_snapshot_free(pwr_snapshot *snap);
  *               all of those, so they commit in this very batch), then the next rows in order as before; rows are picked ahead only
  *               while a commit opens / empties fewer than 12 columns on average, and every row that was jumped checks at its gather
  *               that the gap has held (PWR_ERR_ORDER otherwise); 0: the next rows in order (round 3).  "window" above 16: in order.
+ *   "hard_rows", "hard_up_pm", "hard_down_pm"
+ *               hard_rows 1 (default): a row whose segment check fails warms up over hard_up_pm (300) per mille of the bandwidth more
+ *               than the steered length in all its later fills, hard_down_pm (0) less again after each of its commits -- failures
+ *               are a property of the row (a row that failed once fails again in 46 % of its fills, any row in 8 %: DESIGN.md
+ *               3.2), so the rows that need a long warm-up get one and the steered length of all others comes down; 0: one
+ *               length for all (round 3); 2: marked and counted only (read-only "hard_marked", "hard_fills", "hard_refail")
  *   "fail_stops"
  *               0 (default): a row whose segment check failed waits for its repeat like a stale row -- later rows of the batch whose
  *               band intervals are disjoint from its own may commit ahead of it; 1: its batch ends with it (rounds 3's rule)

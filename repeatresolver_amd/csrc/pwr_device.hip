@@ -79,6 +79,7 @@ struct Hdr {                       // lives in device memory, one per context
     unsigned long long jumpmask;
     unsigned long long events_total, rows_jumped;
     float evrate; int pad1;
+    unsigned long long hard_marked, hard_fills, hard_refail;   // "hard_rows": rows marked; fills of marked rows planned like any other; those of them that failed
     unsigned long long dbg[32];    // phase timers of the traceback (10 ns ticks), only written by builds with -DPWR_DIAG
 };
 
@@ -99,8 +100,8 @@ struct JobMeta {                   // 96 B
     int abort;                     // k_fill_v3: a wave gave up waiting; its siblings leave too
     int active;                    // 0: the job slot is unused in this batch (everything else is left from the last use)
     int wide;                      // 1: the scores may not fit 32 bits: k_fill64 fills this job, the wave pipeline skips it
-    int off, pad;                  // the job's row is rowids[next_row + off]
-    int changed, pad3;             // 0: the traceback left every base where it was (k_trace_blk): the commit has nothing to do
+    int off, hard;                 // the job's row is rowids[next_row + off]; hard: bit 0 = the row is marked (DState::hard), bit 1 = its fill warmed up the long way for that
+    int changed, level;            // (level: how often the row's check had failed when this fill was planned)  changed 0: the traceback left every base where it was (k_trace_blk): the commit has nothing to do
     int nseg, segfail;             // segments the fill was cut into (k_fill_v3); 1: a segment's warm-up had not converged, the job is repeated in one piece
 };
 
@@ -122,6 +123,7 @@ struct DState {
     const long long *brkoff;
     const int *brkx;
     int *nbrk;                     // [T] cleared by the row's first commit
+    int *hard;                     // [T] "hard_rows": > 0 = a segmented fill of this row failed its check lately (k_commit_finish); such a row warms up the long way at once
     int *inscnt;                   // scratch [colcap], kept all-zero between commits
     int *newidx;                   // scratch [colcap]
     // The rows of the NEXT batch, picked by the batch before it (k_commit_finish): [0] 1 = the list is valid (0: the next rows in
@@ -184,6 +186,7 @@ struct JobBufs {
     int seg_budget, seg_minrows;   // segments all jobs of a batch may have together (dealt by length), none with fewer own rows than seg_minrows
     int seg_balance;               // 1: the own parts are cut so that all segments of a job run about the same number of rows, warm-up included
     int plan_ahead;                // 1: the rows of a batch are picked by the batch before it: rows that commute with every row before them first
+    int hard_rows, hard_up, hard_down;  // a row whose check fails warms up over hard_up more columns from then on, hard_down fewer after every commit (1; 2 = only counted)
     int fail_stops;                     // 1: a job that failed its segment check ends its batch (test hook; 0: later rows that commute with it may still commit)
     int plan_slack, plan_evrate_x100;   // ... which keep more than this many columns from them; only while a commit opens / empties fewer columns than this / 100 on average
     const int *rowids;             // the slab's rows (the plan of a job looks at the lengths of the batch's other jobs)
@@ -479,6 +482,7 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
     if (tid == 0) {
         int S = 1;
         const int level = st.hdr->noseg_row == m->k ? st.hdr->noseg_level : 0;     // how often this row's check has failed
+        const int marked = jb.hard_rows ? (st.hard[m->k] > 0 ? 1 : 0) : 0;
         if (jb.seg_rows > 0 && level < 2) {
             // A launch ends with its longest chain of rows: own rows + warm-up of the job with the fewest segments per base.  The
             // chip holds about one worker wave per SIMD (seg_budget segments of NW waves) before the waves start to share issue
@@ -508,7 +512,10 @@ __device__ void plan_segments(const DState &st, const JobBufs &jb, int job)
         const Hdr *hd = st.hdr;
         const bool steered = hd->warm_step > 0;
         s_warm = level == 1 ? ((steered && hd->warm_cur < jb.warm_cols) ? jb.warm_cols : 2 * jb.warm_cols) : (steered ? hd->warm_cur : jb.warm_cols);
-        m->nseg = S; m->segfail = 0;
+        // "hard_rows" 1: a row whose check failed lately does not try the short warm-up again (2: only counted, test hook)
+        const int longway = (marked && jb.hard_rows == 1 && level == 0 && steered) ? 1 : 0;
+        if (longway) s_warm = min(max(s_warm, jb.warm_cols), s_warm + st.hard[m->k]);
+        m->nseg = S; m->segfail = 0; m->level = level; m->hard = marked | (longway << 1);
     }
     if (tid < SEG_MAX) s_cells[tid] = 0;
     __syncthreads();
@@ -3620,6 +3627,11 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
                     // (only the FIRST such row of a batch is tracked: it is the one the next batches begin with until it has
                     // passed, so the escalation to one piece always terminates; another one is simply repeated when its turn comes)
                     hh->seg_fails += 1;
+                    if (jb.hard_rows && m->level == 0) {
+                        if (m->hard & 1) { hh->hard_fills += (m->hard & 2) ? 0 : 1; hh->hard_refail += (m->hard & 2) ? 0 : 1; }
+                        else hh->hard_marked += 1;
+                        st.hard[m->k] = min(1 << 20, st.hard[m->k] + jb.hard_up);
+                    }
                     if (!nfail++) {
                         hh->noseg_level = hh->noseg_row == m->k ? hh->noseg_level + 1 : 1; hh->noseg_row = m->k;
                         if (hh->noseg_level == 1 && hh->warm_step > 0) hh->warm_cur = min(hh->warm_hi, hh->warm_cur + hh->warm_up);
@@ -3634,7 +3646,11 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
                     }
                     hh->cells_reference += m->cells;
                     if (hh->noseg_row == m->k) { hh->noseg_row = -1; hh->noseg_level = 0; }
-                    else if (m->nseg > 1) hh->warm_cur = max(hh->warm_lo, hh->warm_cur - hh->warm_step);
+                    else if (m->nseg > 1 && !(m->hard & 2)) hh->warm_cur = max(hh->warm_lo, hh->warm_cur - hh->warm_step);   // (a pass the long way says nothing about the short one)
+                    if (jb.hard_rows && (m->hard & 1) && m->level == 0 && m->nseg > 1) {
+                        if (!(m->hard & 2)) hh->hard_fills += 1;
+                        st.hard[m->k] = max(0, st.hard[m->k] - jb.hard_down);
+                    }
                     if (m->wide) hh->rows_wide += 1;
                 }
             }
@@ -3948,7 +3964,7 @@ struct pwr_ctx {
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
     int seg_budget = 0;                   // > 0: this many for all the jobs of a batch together, dealt by length (measured slower; 0: seg_rows rows each)
     int seg_minrows = 64;                 // ... none with fewer own rows than this
-    int fail_stops = 0;
+    int fail_stops = 0, hard_rows = 1, hard_up_pm = 300, hard_down_pm = 0;   // (per mille of the bandwidth)
     int plan_slack = PLAN_SLACK, plan_evrate_x100 = (int)(PLAN_EVRATE_MAX * 100.0f);   // test hooks: the gap a row must keep to be picked ahead, the event rate above which none is
     int plan_ahead = 1;                   // the speculative rows of a batch: rows among the next 64 whose interval is disjoint from every uncommitted row before them first (0: the next rows in order)
     int seg_balance = 0;                  // 1: ... cut so that every segment runs about as many rows as the others, its warm-up included (measured slower)
@@ -4178,7 +4194,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
     jb.seg_align = c->seg_align;
     jb.seg_budget = c->seg_budget; jb.seg_minrows = c->seg_minrows; jb.seg_balance = c->seg_balance;
-    jb.fail_stops = c->fail_stops;
+    jb.fail_stops = c->fail_stops; jb.hard_rows = c->hard_rows; jb.hard_up = std::max(1, (int)((long long)c->B * c->hard_up_pm / 1000)); jb.hard_down = (int)((long long)c->B * c->hard_down_pm / 1000);
     jb.plan_ahead = c->plan_ahead; jb.plan_slack = c->plan_slack; jb.plan_evrate_x100 = c->plan_evrate_x100;
     jb.rowids = c->d_rowids;
     jb.seg_rows = c->fill_mode == 4 ? c->seg_rows : 0;
@@ -4371,6 +4387,8 @@ static int upload(pwr_ctx *c)
         if ((rc = dmalloc(c, &d_brkoff, T + 1))) return rc;
         if ((rc = dmalloc(c, &d_brkx, brkx.size()))) return rc;
         if ((rc = dmalloc(c, &st.nbrk, T))) return rc;
+        if ((rc = dmalloc(c, &st.hard, T))) return rc;
+        HIPC(hipMemset(st.hard, 0, sizeof(int) * T));
         HIPC(hipMemcpy(d_brkoff, brkoff.data(), sizeof(long long) * (T + 1), hipMemcpyHostToDevice));
         if (!brkx.empty()) HIPC(hipMemcpy(d_brkx, brkx.data(), sizeof(int) * brkx.size(), hipMemcpyHostToDevice));
         HIPC(hipMemcpy(st.nbrk, nbrk.data(), sizeof(int) * T, hipMemcpyHostToDevice));
@@ -5002,6 +5020,9 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "seg_max")) { if (c->on_device || value < 1 || value > SEG_MAX) return PWR_ERR_ARG; c->seg_max = (int)value; return PWR_OK; }
     if (!strcmp(key, "seg_budget")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->seg_budget = (int)value; c->jb.seg_budget = (int)value; return PWR_OK; }
     if (!strcmp(key, "plan_slack")) { if (value < 0 || value > 1000000) return PWR_ERR_ARG; c->plan_slack = (int)value; c->jb.plan_slack = (int)value; return PWR_OK; }
+    if (!strcmp(key, "hard_rows")) { if (c->on_device || value < 0 || value > 2) return PWR_ERR_ARG; c->hard_rows = (int)value; return PWR_OK; }
+    if (!strcmp(key, "hard_up_pm")) { if (c->on_device || value < 1 || value > 100000) return PWR_ERR_ARG; c->hard_up_pm = (int)value; return PWR_OK; }
+    if (!strcmp(key, "hard_down_pm")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->hard_down_pm = (int)value; return PWR_OK; }
     if (!strcmp(key, "fail_stops")) { if (value < 0 || value > 1) return PWR_ERR_ARG; c->fail_stops = (int)value; c->jb.fail_stops = (int)value; return PWR_OK; }
     if (!strcmp(key, "plan_evrate_x100")) { if (value < 0 || value > 100000000) return PWR_ERR_ARG; c->plan_evrate_x100 = (int)value; c->jb.plan_evrate_x100 = (int)value; return PWR_OK; }
     if (!strcmp(key, "plan_ahead")) { if (value != 0 && value != 1) return PWR_ERR_ARG; c->plan_ahead = (int)value; c->jb.plan_ahead = (int)value; return PWR_OK; }
@@ -5038,6 +5059,13 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "plan_slack")) *value = c->plan_slack;
     else if (!strcmp(key, "plan_evrate_x100")) *value = c->plan_evrate_x100;
     else if (!strcmp(key, "fail_stops")) *value = c->fail_stops;
+    else if (!strcmp(key, "hard_rows")) *value = c->hard_rows;
+    else if (!strcmp(key, "hard_up_pm")) *value = c->hard_up_pm;
+    else if (!strcmp(key, "hard_down_pm")) *value = c->hard_down_pm;
+    else if (!strcmp(key, "hard_marked") || !strcmp(key, "hard_fills") || !strcmp(key, "hard_refail")) {   // read-only counters of "hard_rows"
+        *value = 0;
+        if (c->on_device) { Hdr h; int rc = read_hdr(c, &h); if (rc) return rc; *value = (long)(key[5] == 'm' ? h.hard_marked : key[5] == 'f' ? h.hard_fills : h.hard_refail); }
+    }
     else if (!strcmp(key, "evrate_x100")) {                                    // read-only: columns a commit opens / empties, running mean x 100
         *value = 0;
         if (c->on_device) { Hdr h; int rc = read_hdr(c, &h); if (rc) return rc; *value = (long)(h.evrate * 100.0f); }

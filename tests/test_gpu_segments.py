@@ -63,6 +63,37 @@ def test_steered_warm_up_settles_and_changes_nothing(oracle):
     assert res[1][1] < res[0][1]                                     # shorter warm-ups: fewer cells computed
 
 
+def test_rows_whose_check_failed_warm_up_longer_from_then_on(oracle):
+    """Failures of the check are a property of the row (measured at full scale: a row that failed once fails again in
+    46 % of its later fills, any row in 8 %), so a row that fails gets `hard_up_pm` per mille of the bandwidth on top of
+    the steered length from then on ("hard_rows" 1, default; 2: only counted; 0: round 3).  Same MSA as the reference's
+    after every round whatever is marked."""
+    from repeatresolver_amd.realigner import PWReAligner
+    rows = split_rows(golden_input("toy_b_b1000"))
+    lib = oracle.lib
+    h = oracle.create(rows, 1000)
+    lib.pwo_trim(h)
+    exp = []
+    for rnd in range(3):
+        lib.pwo_realign_round(h)
+        exp.append((lib.pwo_total_score(h), oracle.export(h)))
+    lib.pwo_destroy(h)
+    seen = {}
+    for mode in (0, 2, 1):
+        g = PWReAligner(rows, bandwidth=1000, window=2, seg_rows=128, seg_max=64, warm_pct=200, warm_min_pct=10, hard_rows=mode,
+                        hard_up_pm=500)
+        g.trim_ends()
+        for rnd in range(3):
+            g.realign_round()
+            assert g.total_score() == exp[rnd][0], (mode, rnd)
+            assert g.export_rows() == exp[rnd][1], (mode, rnd)
+        seen[mode] = (g.stats()["seg_fails"], g.get_option("hard_marked"), g.get_option("hard_fills"), g.get_option("hard_refail"))
+        g.close()
+    assert seen[0][0] > 0 and seen[0][1:] == (0, 0, 0), seen
+    assert seen[2][0] == seen[0][0] and seen[2][1] > 0 and seen[2][2] >= seen[2][3], seen   # counting changes nothing
+    assert seen[1][1] > 0 and seen[1][2:] == (0, 0), seen                                     # (marked rows never go the short way)
+
+
 @pytest.mark.parametrize("onewg", [0, 1])
 @pytest.mark.parametrize("waves", [3, 4, 5, 8, 9, 17])
 def test_segmented_fill_wave_geometries(waves, onewg, oracle):
