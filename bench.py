@@ -320,7 +320,7 @@ def main():
                        "useful_frac": (st["cells_reference"] / st["cells_computed"]) if st["cells_computed"] else None,
                        "commits_per_batch": (st["rows_committed"] / st["batches"]) if st["batches"] else None,
                        "seg_jobs": st["seg_jobs"], "segs": st["segs"], "seg_fails": st["seg_fails"],
-                       "options": {k_: opt_or_none(ctxs[0], k_) for k_ in ("window", "fill", "waves", "spec_len", "seg_rows", "seg_max", "warm_pct", "src_start", "warm_adapt", "warm_min_pct", "warm_down_pm", "warm_up_pm", "warm_now", "plan_ahead", "plan_slack", "plan_evrate_x100", "evrate_x100", "fail_stops", "hard_rows", "hard_up_pm", "hard_down_pm", "hard_marked", "hard_fills", "hard_refail")} if ctxs else None,
+                       "options": {k_: opt_or_none(ctxs[0], k_) for k_ in ("window", "fill", "waves", "spec_len", "seg_rows", "seg_max", "warm_pct", "src_start", "warm_adapt", "warm_min_pct", "warm_down_pm", "warm_up_pm", "warm_now", "plan_ahead", "plan_slack", "plan_evrate_x100", "evrate_x100", "fail_stops", "hard_rows", "hard_up_pm", "hard_down_pm", "hard_marked", "hard_fills", "hard_refail", "host_enqueue_us", "host_wait_us")} if ctxs else None,
                        "generate_s": round(gen_s, 1), "input": args.input, "initial_aligner": ia_info, "complete": bool(final)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,

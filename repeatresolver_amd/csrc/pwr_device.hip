@@ -3934,7 +3934,9 @@ struct pwr_ctx {
     JobBufs jb{};
     int njobs = 0;
     int *d_jobrows = nullptr;
-    int *d_rowids = nullptr;              // [T] identity: job j of a window starting at row k0 realigns d_rowids[k0 + j]
+    int *d_rowids = nullptr;              // the rows of the k loop in order -- the rows that HAVE bases (a row without any is done wherever it stands, PW:1488; the sections
+                                          // of a Window.py cut are half made of them): job j of a batch that begins at position p realigns d_rowids[p + off_j]
+    std::vector<int> ids, pos_lo;         // ... on the host; pos_lo[r] = how many rows before row r have bases (T + 1 entries)
     unsigned long long *d_score = nullptr;
     hipStream_t stream = nullptr;
     std::vector<int> rowlen;
@@ -3952,10 +3954,12 @@ struct pwr_ctx {
     int cap_slack = 8192;                 // 0 = allocate tightly (tests: forces the regrow path)
     int spec_len = 6;                     // percent a speculative row may be longer than the first row of its batch (option "spec_len")
     int fill_mode = 4;                    // 4: k_fill_v3 (one work-group per wave, default), 3: k_fill_v2 (one work-group per DP; cross-check and fallback)
+    double host_enqueue_s = 0, host_wait_s = 0;   // diagnostic: time the host spent enqueueing batches / waiting for their headers (read-only options)
     unsigned host_seq = 0;                // sequence number of the header copies the commit kernels leave in pinned memory
     int seen_fallback = 0, seen_need64 = 0;   // Hdr::fallback / need64 as the host last saw them: the batches it enqueues bring k_fill_v2 / k_fill64 along
     unsigned trace_epoch = 0;             // k_trace_par launch counter (22 bits)
     unsigned fill_epoch = 0;              // k_fill_v3 launch counter (15 bits; the mailboxes are cleared when it wraps)
+    int wave_cols = 0;                    // 4 with 9 waves: 256-column strips also at bandwidths up to 1000, so that no wave has two strips of a DP row (experiment)
     int wp_waves = 5;                     // waves per DP of the wave-pipeline fills: 9/8/5/4/3 with 2/3/4/6/8 columns per lane (5: measured best with segments side by side)
     int one_wg = 0;                       // k_fill_v3: the waves of a segment as one work-group (hand-over through LDS); 0: one work-group per wave
     int one_wg_lds = 0;                   // ... with this many bytes of dynamic LDS on top (keeps other work-groups off its compute unit)
@@ -4169,7 +4173,8 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     JobBufs &jb = c->jb;
     if (c->B > 1000) c->wp_waves = 9;
     if (c->wp_waves == 17 && c->fill_mode != 4) c->wp_waves = 9;          // 17 x 64 threads do not fit one work-group
-    const int wpC = c->wp_waves == 17 ? 1 : c->wp_waves == 8 ? 3 : c->wp_waves == 5 ? 4 : c->wp_waves == 4 ? 6 : c->wp_waves == 3 ? 8 : (c->B <= 1024 ? 2 : 4);
+    if (c->wp_waves != 9) c->wave_cols = 0;
+    const int wpC = c->wp_waves == 17 ? 1 : c->wp_waves == 8 ? 3 : c->wp_waves == 5 ? 4 : c->wp_waves == 4 ? 6 : c->wp_waves == 3 ? 8 : ((c->B <= 1024 && c->wave_cols != 4) ? 2 : 4);
     const int NC = c->wp_waves * 64 * wpC;
     jb.Lmax = std::max(c->Lmax, 1);
     jb.force64 = c->force64;
@@ -4410,10 +4415,11 @@ static int upload(pwr_ctx *c)
     HIPC(hipMemcpy(st.rank, ident.data(), sizeof(int) * W, hipMemcpyHostToDevice));
     HIPC(hipMemset(st.inscnt, 0, sizeof(int) * st.colcap));
     {
-        std::vector<int> ids(T);
-        for (int r = 0; r < T; ++r) ids[r] = r;
-        if ((rc = dmalloc(c, &c->d_rowids, T))) return rc;
-        HIPC(hipMemcpy(c->d_rowids, ids.data(), sizeof(int) * T, hipMemcpyHostToDevice));
+        c->ids.clear(); c->pos_lo.assign(T + 1, 0);
+        for (int r = 0; r < T; ++r) { c->pos_lo[r] = (int)c->ids.size(); if (c->rowlen[r] > 0) c->ids.push_back(r); }
+        c->pos_lo[T] = (int)c->ids.size();
+        if ((rc = dmalloc(c, &c->d_rowids, std::max<size_t>(1, c->ids.size())))) return rc;
+        if (!c->ids.empty()) HIPC(hipMemcpy(c->d_rowids, c->ids.data(), sizeof(int) * c->ids.size(), hipMemcpyHostToDevice));
     }
     HIPC(hipStreamCreate(&c->stream));
     if ((rc = alloc_jobs(c, std::max(1, c->window)))) return rc;
@@ -4509,7 +4515,7 @@ static int launch_fill(pwr_ctx *c, int njobs)
         if (c->stall_test > 0) c->stall_test -= 1;
         const int nv = njobs * c->jb.smax;                                 // one slot per (job, segment)
         const dim3 grid(8, c->wp_waves, (nv + 7) / 8);
-        const bool wg1 = c->one_wg && c->wp_waves <= 9 && c->B <= 1024;
+        const bool wg1 = c->one_wg && c->wp_waves <= 9 && c->B <= 1024 && c->wave_cols != 4;
         if (wg1) {
             // the waves of a segment as one work-group (LDS hand-over); "onewg_lds" bytes of dynamic LDS on top keep other
             // work-groups off the segment's compute unit (experiment: a CU to itself, one wave per SIMD with waves = 4)
@@ -4525,7 +4531,7 @@ static int launch_fill(pwr_ctx *c, int njobs)
         else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v3<8, 3, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v3<4, 6, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v3<3, 8, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
-        else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v3<9, 2, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
+        else if (c->B <= 1024 && c->wave_cols != 4) hipLaunchKernelGGL((k_fill_v3<9, 2, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_v3<9, 4, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         c->jb.stall_test = 0;
         if (c->jb.smax > 1 && c->jb.seg_rows > 0)
@@ -4540,7 +4546,7 @@ static int launch_fill(pwr_ctx *c, int njobs)
         else if (c->wp_waves == 8) hipLaunchKernelGGL((k_fill_v2<8, 3>), dim3(njobs), dim3(8 * 64), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 4) hipLaunchKernelGGL((k_fill_v2<4, 6>), dim3(njobs), dim3(4 * 64), 0, c->stream, c->st, c->jb);
         else if (c->wp_waves == 3) hipLaunchKernelGGL((k_fill_v2<3, 8>), dim3(njobs), dim3(3 * 64), 0, c->stream, c->st, c->jb);
-        else if (c->B <= 1024) hipLaunchKernelGGL((k_fill_v2<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
+        else if (c->B <= 1024 && c->wave_cols != 4) hipLaunchKernelGGL((k_fill_v2<9, 2>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_v2<9, 4>), dim3(njobs), dim3(9 * 64), 0, c->stream, c->st, c->jb);
     } else if (c->fill_mode != 4) return PWR_ERR_ARG;
     HIPC(hipGetLastError());
@@ -4645,13 +4651,13 @@ static int enqueue_batch(pwr_ctx *c, Hdr *host_copy, unsigned host_seq)
 // Start a slab: rows [k0, k0 + n), first batch sized like the host did before (the running mean carries over).  (After a
 // regrow a slab goes on where it stood instead: the device's row pointer and its mask of rows already committed ahead of
 // order stay as they are -- each row is realigned once per round, PW:1695.)
-static int slab_init(pwr_ctx *c, int k0, int n)
+static int slab_init(pwr_ctx *c, int k0, int n)                              // (k0, n: POSITIONS in the list of rows that have bases)
 {
     const int kend = k0 + n;
     int nb = (int)(c->batch_ema + 2.6);
     nb = std::max(1, std::min(nb, std::min(c->window, n)));
     for (int j = 1; j < nb; ++j)
-        if (c->rowlen[k0 + j] > c->rowlen[k0] + (int)((long long)c->rowlen[k0] * c->spec_len / 100) + 64) { nb = j; break; }
+        if (c->rowlen[c->ids[k0 + j]] > c->rowlen[c->ids[k0]] + (int)((long long)c->rowlen[c->ids[k0]] * c->spec_len / 100) + 64) { nb = j; break; }
     const float ema0 = (float)c->batch_ema;
     struct { int next_row, row_end, nb, need_grow, window; } init = {k0, kend, nb, 0, c->window};
     static_assert(sizeof(init) == offsetof(Hdr, fallback) - offsetof(Hdr, next_row), "slab fields of Hdr");
@@ -4669,7 +4675,7 @@ static int slab_init(pwr_ctx *c, int k0, int n)
 // device sequences the rows itself (Hdr::next_row); the host keeps PWR_INFLIGHT batches queued and looks at a copy of the
 // header that trails by that many batches, so no launch waits for a round trip.  Batches enqueued after the slab's last row
 // was committed find nothing to do.
-static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
+static int realign_positions(pwr_ctx *c, int k0, int n, bool resume = false)   // (k0, n: positions in the list of rows that have bases)
 {
     if (!c->h_ring) {
         void *p = nullptr;
@@ -4688,7 +4694,9 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
     while (true) {
         while (issued < most && issued - looked < PWR_INFLIGHT) {
             const int slot = (int)(issued % PWR_INFLIGHT);
+            const auto t_e = std::chrono::steady_clock::now();
             if ((rc = enqueue_batch(c, &ring[slot], ++c->host_seq))) return rc;   // (its commit kernel leaves the header in ring[slot], this number last)
+            c->host_enqueue_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_e).count();
             seqs[slot] = c->host_seq;
             ++issued;
         }
@@ -4698,6 +4706,7 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
             // wait for that batch's header: poll the sequence number (pinned memory), look at the stream now and then in case
             // it has died
             volatile unsigned *sq = &ring[slot].seq;
+            const auto t_w = std::chrono::steady_clock::now();
             std::chrono::steady_clock::time_point t_wait{};
             for (unsigned long long spin = 1; *sq != seqs[slot]; ++spin) {
                 if ((spin & 0xfffffull) == 0) {
@@ -4723,6 +4732,7 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
 #endif
             }
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            c->host_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_w).count();
         }
         const Hdr h = ring[slot];
         ++looked;
@@ -4732,9 +4742,9 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
             // the batches queued behind this one do nothing while the flag is up
             HIPC(hipStreamSynchronize(c->stream));
             long long growth = 0;
-            for (int j = 0; j < c->window && h.next_row + j < kend; ++j) growth += c->rowlen[h.next_row + j];
+            for (int j = 0; j < c->window && h.next_row + j < kend; ++j) growth += c->rowlen[c->ids[h.next_row + j]];
             if ((rc = grow_state(c, growth))) return rc;
-            return realign_range(c, h.next_row, kend - h.next_row, true);
+            return realign_positions(c, h.next_row, kend - h.next_row, true);
         }
         if (h.next_row >= kend) break;
         if (h.ncommitted == 0 && most < 4LL * n + 256) ++most;                  // ... except one whose first job stalled, failed its segment check, or came without the kernel it needed
@@ -4746,6 +4756,14 @@ static int realign_range(pwr_ctx *c, int k0, int n, bool resume = false)
     c->seen_fallback = h.fallback; c->seen_need64 = h.need64;
     stats_from_hdr(c, h);
     return h.status;
+}
+
+// rows k0 .. k0 + n - 1: the rows among them that have bases, a run of the list
+static int realign_range(pwr_ctx *c, int k0, int n)
+{
+    const int p0 = c->pos_lo[k0], pn = c->pos_lo[k0 + n] - p0;
+    if (pn == 0) return check_status(c);
+    return realign_positions(c, p0, pn);
 }
 
 extern "C" int pwr_realign_row(pwr_ctx *c, int k)
@@ -4791,9 +4809,9 @@ extern "C" int pwr_split_begin(pwr_ctx *c, int k0, int n, int rank, int world)
     if (rc) return rc;
     c->split_rank = rank; c->split_world = world;
     c->jb.split_rank = rank; c->jb.split_world = world;
-    c->split_k0 = k0; c->split_kend = k0 + n;
+    c->split_k0 = c->pos_lo[k0]; c->split_kend = c->pos_lo[k0 + n];             // (positions in the list of rows that have bases)
     if (n == 0) return PWR_OK;
-    return slab_init(c, k0, n);
+    return slab_init(c, c->split_k0, c->split_kend - c->split_k0);
 }
 
 extern "C" int pwr_split_slot_bytes(pwr_ctx *c, size_t *slot_bytes, int *slots_per_rank)
@@ -4835,7 +4853,7 @@ extern "C" int pwr_split_commit(pwr_ctx *c, const void *recv_dev, int *rows_left
     if (h.need_grow) {
         // every replica finds the same shortage in the same batch and regrows alike; the slab goes on where it stands
         long long growth = 0;
-        for (int j = 0; j < c->window && h.next_row + j < c->split_kend; ++j) growth += c->rowlen[h.next_row + j];
+        for (int j = 0; j < c->window && h.next_row + j < c->split_kend; ++j) growth += c->rowlen[c->ids[h.next_row + j]];
         if ((rc = grow_state(c, growth))) return rc;
     }
     *rows_left = std::max(0, h.row_end - h.next_row);
@@ -5038,6 +5056,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "warm_up_pm")) { if (c->on_device || value < 1 || value > 10000) return PWR_ERR_ARG; c->warm_up_pm = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_min_pct")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->warm_min_pct = (int)value; return PWR_OK; }
     if (!strcmp(key, "warm_pct")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->warm_pct = (int)value; return PWR_OK; }
+    if (!strcmp(key, "wave_cols")) { if (c->on_device || (value != 0 && value != 4)) return PWR_ERR_ARG; c->wave_cols = (int)value; return PWR_OK; }
     if (!strcmp(key, "waves")) { if (c->on_device || (value != 3 && value != 4 && value != 5 && value != 8 && value != 9 && value != 17)) return PWR_ERR_ARG; c->wp_waves = (int)value; return PWR_OK; }
     return PWR_ERR_ARG;
 }
@@ -5078,6 +5097,8 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "warm_pct")) *value = c->warm_pct;
     else if (!strcmp(key, "src_start")) *value = c->src_start;
     else if (!strcmp(key, "warm_adapt")) *value = c->warm_adapt;
+    else if (!strcmp(key, "host_enqueue_us")) *value = (long)(c->host_enqueue_s * 1e6);   // read-only, since the context was made
+    else if (!strcmp(key, "host_wait_us")) *value = (long)(c->host_wait_s * 1e6);
     else if (!strcmp(key, "warm_now")) {                                      // percent of the bandwidth a warm-up covers right now
         if (!c->on_device) *value = c->warm_pct;
         else { Hdr h; int rc = read_hdr(c, &h); if (rc) return rc; *value = h.warm_step > 0 ? (long)(((long long)h.warm_cur * 100 + c->B / 2) / c->B) : c->warm_pct; }

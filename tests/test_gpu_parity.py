@@ -375,6 +375,57 @@ def test_rows_without_bases_and_unsupported_states():
     g.close()
 
 
+def test_slabs_over_rows_without_bases(oracle):
+    """The k loop runs over the rows that HAVE bases (a row without any is done wherever it stands, PW:1488; the sections of
+    a Window.py cut are half made of such rows): slabs that begin, end or consist of empty rows, single empty rows, and the
+    split-round calls over them leave the MSA the reference's round leaves."""
+    from repeatresolver_amd.realigner import PWReAligner
+    rows = split_rows(golden_input("toy_a_b1000"))
+    blank = b" " * len(rows[0])
+    T0 = len(rows)
+    empty = {0, 1, 7, 8, 9, 20, T0 - 1}
+    rows = [blank if k in empty else r for k, r in enumerate(rows)]
+    lib = oracle.lib
+    h = oracle.create(rows, 200)
+    lib.pwo_trim(h)
+    exp = []
+    for rnd in range(2):
+        lib.pwo_realign_round(h)
+        exp.append((lib.pwo_total_score(h), oracle.export(h)))
+    cells = lib.pwo_cells(h)
+    lib.pwo_destroy(h)
+    for mode in ("round", "slabs", "rows", "split"):
+        g = PWReAligner(rows, bandwidth=200, window=3)
+        g.trim_ends()
+        for rnd in range(2):
+            if mode == "round":
+                g.realign_round()
+            elif mode == "slabs":
+                for k0, n in ((0, 2), (2, 5), (7, 3), (10, 10), (20, 1), (21, T0 - 21)):
+                    g.realign_rows(k0, n)
+            elif mode == "rows":
+                for k in range(T0):
+                    g.realign_row(k)
+            else:
+                import torch
+                for k0, n in ((0, 2), (2, 6), (8, 2), (10, T0 - 10)):
+                    g.split_begin(k0, n, 0, 1)
+                    slot, per_rank = g.split_slot_bytes()
+                    buf = torch.zeros(slot * per_rank, dtype=torch.uint8, device="cuda")
+                    left, guard = n, 4 * n + 8
+                    while left > 0 and guard > 0:
+                        g.split_stage(buf.data_ptr())
+                        left = g.split_commit(buf.data_ptr())
+                        guard -= 1
+                    assert left <= 0
+            assert g.total_score() == exp[rnd][0], (mode, rnd)
+            assert g.export_rows() == exp[rnd][1], (mode, rnd)
+        st = g.stats()
+        assert st["cells_reference"] == cells, mode
+        assert st["rows_committed"] == 2 * (T0 - len(empty)), mode
+        g.close()
+
+
 def test_medium_properties_and_kernel_cross_check():
     """A shape too large for the oracle to follow row by row in the test budget (2.3 k rows x 37 k
     columns, 8*10^9 cells per round): size-independent properties, and the two fill kernels and several

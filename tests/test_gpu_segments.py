@@ -102,6 +102,13 @@ def test_segmented_fill_wave_geometries(waves, onewg, oracle):
     _row_by_row("lowcov_b300", 300, 2, oracle, waves=waves, onewg=onewg, seg_rows=128, seg_max=64, warm_pct=200)
 
 
+def test_nine_waves_with_strips_of_256_columns(oracle):
+    """9 waves x 4 columns per lane at a bandwidth of 1000 ("wave_cols" 4): strips so wide that no wave has two of a DP row."""
+    _row_by_row("toy_b_b1000", 1000, 1, oracle, waves=9, wave_cols=4, seg_rows=128, seg_max=64, warm_pct=200)
+    _row_by_row("lowcov_b300", 300, 2, oracle, waves=9, wave_cols=4, seg_rows=128, seg_max=64, warm_pct=200)
+    _row_by_row("toy_b_b1000", 1000, 1, oracle, waves=9, wave_cols=4, seg_rows=0)
+
+
 def test_failed_segment_check_repeats_the_row_in_one_piece(oracle):
     """A warm-up that is far too short (a fifth of the bandwidth): the check of the segments' starts must catch it, the row
     is realigned again with its fill in one piece, and the results are the reference's all the same."""
