@@ -49,7 +49,14 @@ while time.time() < t_end:
                 warm_pct=int(rng.choice([20, 100, 190, 300])), ptrace=int(rng.choice([0, 1, 2, 2, 2])), waves=int(rng.choice([3, 4, 5, 5, 8, 9, 17])),
                 onewg=int(rng.choice([0, 0, 1])), seg_align=int(rng.choice([16, 32, 64])), slack=int(rng.choice([0, 8192])),
                 src_start=int(rng.choice([0, 1, 1])), warm_adapt=int(rng.choice([0, 1, 1])), warm_min_pct=int(rng.choice([10, 50, 100])),
-                seg_budget=int(rng.choice([0, 0, 12, 200])), seg_minrows=int(rng.choice([16, 64])), seg_balance=int(rng.choice([0, 1, 1])), plan_ahead=int(rng.choice([0, 1, 1])), plan_slack=int(rng.choice([1024, 1024, 64])), evcap=int(rng.choice([1024, 1024, 1024, 0, 3])))
+                seg_budget=int(rng.choice([0, 0, 12, 200])), seg_minrows=int(rng.choice([16, 64])), seg_balance=int(rng.choice([0, 1, 1])), plan_ahead=int(rng.choice([0, 1, 1])), plan_slack=int(rng.choice([1024, 1024, 64])), evcap=int(rng.choice([1024, 1024, 1024, 0, 3])),
+                hard_rows=int(rng.choice([0, 1, 1, 2])), hard_up_pm=int(rng.choice([100, 300, 1000])), hard_down_pm=int(rng.choice([0, 0, 50])), fail_stops=int(rng.choice([0, 0, 1])),
+                spec_inorder=int(rng.choice([64, 64, 0, 1])), wave_cols=int(rng.choice([0, 0, 4])))
+    if opts["waves"] != 9: opts["wave_cols"] = 0
+    # (rows without bases: the k loop runs over the others)
+    if rng.random() < 0.3:
+        blank = b" " * len(rows[0])
+        for k in rng.choice(len(rows), size=max(1, len(rows) // 5), replace=False): rows[int(k)] = blank
     print("case", n, cfg, "bw", bw, opts, "rows", len(rows), "x", len(rows[0]), flush=True)
     tm = threading.Timer(45, watchdog); tm.daemon = True; tm.start()
     faulthandler.dump_traceback_later(70, exit=True)
