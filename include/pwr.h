@@ -152,6 +152,8 @@ void pwr_snapshot_free(pwr_snapshot *snap);
  *               all of those, so they commit in this very batch), then the next rows in order as before; rows are picked ahead only
  *               while a commit opens / empties fewer than 12 columns on average, and every row that was jumped checks at its gather
  *               that the gap has held (PWR_ERR_ORDER otherwise); 0: the next rows in order (round 3).  "window" above 16: in order.
+ *               ("plan_slack", "plan_evrate_x100": the gap and the rate, test hooks; with a smaller gap rows also stop jumping as soon as 64
+ *               commits at the present rate would fill half of it, "plan_gate_rel" 1.)
  *   "hard_rows", "hard_up_pm", "hard_down_pm"
  *               hard_rows 1 (default): a row whose segment check fails warms up over hard_up_pm (300) per mille of the bandwidth more
  *               than the steered length in all its later fills, hard_down_pm (0) less again after each of its commits -- failures

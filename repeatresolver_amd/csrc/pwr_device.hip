@@ -187,6 +187,7 @@ struct JobBufs {
     int seg_balance;               // 1: the own parts are cut so that all segments of a job run about the same number of rows, warm-up included
     int plan_ahead;                // 1: the rows of a batch are picked by the batch before it: rows that commute with every row before them first
     int hard_rows, hard_up, hard_down;  // a row whose check fails warms up over hard_up more columns from then on, hard_down fewer after every commit (1; 2 = only counted)
+    int plan_gate_rel;                  // 1: rows jump only while 64 commits' worth of events stay below half the gap they keep (0: test hook)
     int spec_inorder;                   // with plan_ahead: at most this many speculative rows in order per batch, beside the rows picked ahead
     int fail_stops;                     // 1: a job that failed its segment check ends its batch (test hook; 0: later rows that commute with it may still commit)
     int plan_slack, plan_evrate_x100;   // ... which keep more than this many columns from them; only while a commit opens / empties fewer columns than this / 100 on average
@@ -3720,7 +3721,9 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
                 s_ahead = hh->ahead;
                 // rows jump only while the MSA is calm: 64 commits' worth of opened / emptied columns must stay far below the gap
                 // a jump keeps, and the jumps still pending must not have seen a quarter of it already (looked up by the lanes below)
-                s_pl[7] = hh->evrate * 100.0f < (float)jb.plan_evrate_x100 ? 1 : 0;
+                // (... and never while 64 commits at the present rate would fill half the gap a jump keeps: a gap set far below the default
+                // would otherwise be closed by ordinary rounds and end in PWR_ERR_ORDER -- found by the randomised sweep)
+                s_pl[7] = hh->evrate * 100.0f < fminf((float)jb.plan_evrate_x100, jb.plan_gate_rel ? (float)jb.plan_slack * (100.0f / 128.0f) : 3.0e38f) ? 1 : 0;
                 s_jm = hh->jumpmask; s_ev = (unsigned)hh->events_total;
                 if (!s_pl[0]) st.bplan[0] = 0;                                     // the next rows in order
             }
@@ -3969,7 +3972,7 @@ struct pwr_ctx {
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
     int seg_budget = 0;                   // > 0: this many for all the jobs of a batch together, dealt by length (measured slower; 0: seg_rows rows each)
     int seg_minrows = 64;                 // ... none with fewer own rows than this
-    int spec_inorder = 64;
+    int spec_inorder = 64, plan_gate_rel = 1;
     int fail_stops = 0, hard_rows = 1, hard_up_pm = 300, hard_down_pm = 0;   // (per mille of the bandwidth)
     int plan_slack = PLAN_SLACK, plan_evrate_x100 = (int)(PLAN_EVRATE_MAX * 100.0f);   // test hooks: the gap a row must keep to be picked ahead, the event rate above which none is
     int plan_ahead = 1;                   // the speculative rows of a batch: rows among the next 64 whose interval is disjoint from every uncommitted row before them first (0: the next rows in order)
@@ -4201,7 +4204,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
     jb.seg_align = c->seg_align;
     jb.seg_budget = c->seg_budget; jb.seg_minrows = c->seg_minrows; jb.seg_balance = c->seg_balance;
-    jb.spec_inorder = c->spec_inorder;
+    jb.spec_inorder = c->spec_inorder; jb.plan_gate_rel = c->plan_gate_rel;
     jb.fail_stops = c->fail_stops; jb.hard_rows = c->hard_rows; jb.hard_up = std::max(1, (int)((long long)c->B * c->hard_up_pm / 1000)); jb.hard_down = (int)((long long)c->B * c->hard_down_pm / 1000);
     jb.plan_ahead = c->plan_ahead; jb.plan_slack = c->plan_slack; jb.plan_evrate_x100 = c->plan_evrate_x100;
     jb.rowids = c->d_rowids;
@@ -5044,6 +5047,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "hard_rows")) { if (c->on_device || value < 0 || value > 2) return PWR_ERR_ARG; c->hard_rows = (int)value; return PWR_OK; }
     if (!strcmp(key, "hard_up_pm")) { if (c->on_device || value < 1 || value > 100000) return PWR_ERR_ARG; c->hard_up_pm = (int)value; return PWR_OK; }
     if (!strcmp(key, "hard_down_pm")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->hard_down_pm = (int)value; return PWR_OK; }
+    if (!strcmp(key, "plan_gate_rel")) { if (value < 0 || value > 1) return PWR_ERR_ARG; c->plan_gate_rel = (int)value; c->jb.plan_gate_rel = (int)value; return PWR_OK; }
     if (!strcmp(key, "spec_inorder")) { if (value < 0 || value > 64) return PWR_ERR_ARG; c->spec_inorder = (int)value; c->jb.spec_inorder = (int)value; return PWR_OK; }
     if (!strcmp(key, "fail_stops")) { if (value < 0 || value > 1) return PWR_ERR_ARG; c->fail_stops = (int)value; c->jb.fail_stops = (int)value; return PWR_OK; }
     if (!strcmp(key, "plan_evrate_x100")) { if (value < 0 || value > 100000000) return PWR_ERR_ARG; c->plan_evrate_x100 = (int)value; c->jb.plan_evrate_x100 = (int)value; return PWR_OK; }
@@ -5083,6 +5087,7 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "plan_evrate_x100")) *value = c->plan_evrate_x100;
     else if (!strcmp(key, "fail_stops")) *value = c->fail_stops;
     else if (!strcmp(key, "spec_inorder")) *value = c->spec_inorder;
+    else if (!strcmp(key, "plan_gate_rel")) *value = c->plan_gate_rel;
     else if (!strcmp(key, "hard_rows")) *value = c->hard_rows;
     else if (!strcmp(key, "hard_up_pm")) *value = c->hard_up_pm;
     else if (!strcmp(key, "hard_down_pm")) *value = c->hard_down_pm;

@@ -1,6 +1,6 @@
 """dev (GPU box): randomised parity sweep -- small simulated MSAs of random shape, random bandwidth / window / segment plan /
 traceback kernel / wave geometry, three rounds each, exported text and total score against the CPU oracle after every round.
-usage: stress.py [seconds] [seed]"""
+usage: stress.py [seconds] [seed] [first case to run] [key=value overrides ...]"""
 import sys, os, time, threading, subprocess, faulthandler, signal
 import numpy as np
 
@@ -26,7 +26,10 @@ from repeatresolver_amd.realigner import PWReAligner
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 oracle = Oracle(); lib = oracle.lib
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+over = {a.split('=')[0]: int(a.split('=')[1]) for a in sys.argv[4:]}
 t_end = time.time() + budget
+orders = 0
 n = bad = 0
 tot = {"seg_jobs": 0, "seg_fails": 0, "rows_ahead": 0, "rows_committed": 0, "rows_recomputed": 0}
 while time.time() < t_end:
@@ -57,23 +60,38 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         blank = b" " * len(rows[0])
         for k in rng.choice(len(rows), size=max(1, len(rows) // 5), replace=False): rows[int(k)] = blank
+    if n < first:
+        n += 1
+        continue
+    opts.update(over)
     print("case", n, cfg, "bw", bw, opts, "rows", len(rows), "x", len(rows[0]), flush=True)
     tm = threading.Timer(45, watchdog); tm.daemon = True; tm.start()
     faulthandler.dump_traceback_later(70, exit=True)
     g = PWReAligner(rows, bandwidth=bw, **opts)
     g.trim_ends()
     h = oracle.create(rows, bw); lib.pwo_trim(h)
-    ok = True
+    ok = True; reported = False
     for rnd in range(3):
-        print(" gpu", end="", flush=True); g.realign_round()
+        print(" gpu", end="", flush=True)
+        try:
+            g.realign_round()
+        except Exception as e:
+            # a jump whose gap did not hold is REPORTED (PWR_ERR_ORDER); with the gap the sweep sets far below the default that may happen
+            if getattr(e, "code", 0) == -10 and opts["plan_slack"] < 1024:
+                print(" [order reported, plan_slack", opts["plan_slack"], "]", end="", flush=True); orders += 1; reported = True; break
+            raise
         print(" oracle", end="", flush=True); lib.pwo_realign_round(h)
         print(" compare", end="", flush=True)
+        if reported: break
         if g.total_score() != lib.pwo_total_score(h) or g.export_rows() != oracle.export(h):
             ok = False; break
     print(" done", flush=True)
+    if reported:
+        lib.pwo_destroy(h); g.close(); tm.cancel(); faulthandler.cancel_dump_traceback_later(); n += 1
+        continue
     st = g.stats()
     for k in tot: tot[k] += st[k]
-    if ok and st["cells_reference"] != lib.pwo_cells(h): ok = False
+    if ok and not reported and st["cells_reference"] != lib.pwo_cells(h): ok = False
     n += 1
     if n % 10 == 0: print("...", n, "cases", bad, "mismatches", flush=True)
     if not ok:
@@ -81,4 +99,4 @@ while time.time() < t_end:
         print("MISMATCH", cfg, "bw", bw, opts, "round", rnd, flush=True)
     lib.pwo_destroy(h); g.close()
     tm.cancel(); faulthandler.cancel_dump_traceback_later()
-print(f"{n} cases, {bad} mismatches; {tot}")
+print(f"{n} cases, {bad} mismatches, {orders} jumps reported as not holding (small plan_slack only); {tot}")

@@ -282,7 +282,7 @@ def test_rows_picked_ahead_commute_and_commit(oracle):
     lib.pwo_destroy(h)
     jumped = {}
     for plan, window in ((1, 3), (0, 3), (1, 6)):
-        g = PWReAligner(rows, bandwidth=300, window=window, plan_ahead=plan, plan_slack=200)
+        g = PWReAligner(rows, bandwidth=300, window=window, plan_ahead=plan, plan_slack=200, plan_gate_rel=0)
         g.trim_ends()
         for rnd in range(3):
             g.realign_round()
@@ -318,7 +318,7 @@ def test_rows_commit_past_a_row_whose_check_failed(oracle):
     seen = {}
     for stops, plan in ((1, 0), (0, 0), (0, 1)):
         g = PWReAligner(rows, bandwidth=300, window=6, seg_rows=64, seg_max=64, warm_pct=25, warm_adapt=0, plan_ahead=plan,
-                        plan_slack=200, fail_stops=stops)
+                        plan_slack=200, plan_gate_rel=0, fail_stops=stops)
         g.trim_ends()
         for rnd in range(2):
             g.realign_round()
@@ -347,7 +347,7 @@ def test_a_jump_that_does_not_hold_is_reported_not_swallowed(oracle):
                            length_scale=0.02, min_aligned=40, seed=100 + seed)
         rows = [bytes(r) for r in dg.build_msa(dg.simulate(cfg))]
         bw = (6, 10, 16, 24)[seed % 4]
-        g = PWReAligner(rows, bandwidth=bw, window=(4, 8)[seed % 2], plan_slack=0, plan_evrate_x100=100000000)
+        g = PWReAligner(rows, bandwidth=bw, window=(4, 8)[seed % 2], plan_slack=0, plan_evrate_x100=100000000, plan_gate_rel=0)
         g.trim_ends()
         h = oracle.create(rows, bw)
         lib.pwo_trim(h)
