@@ -192,6 +192,11 @@ def main():
             load[r] += cost[p]
         units = [(f"section {p} columns [{bounds[p]},{bounds[p + 1]})", secs[p]) for p in range(len(secs)) if owner[p] == rank and (args.only_section is None or p == args.only_section)]
         owned = [[p for p in range(len(secs)) if owner[p] == r] for r in range(world)]
+        if args.window is None:
+            # inside a section every row overlaps every other (0.99 commits per batch whatever the window): a third job per batch is
+            # work for nothing, and with several sections side by side on a GPU it takes the SIMDs of the others' first jobs
+            # (six sections on one GPU: window 1 428, 2 425, 3 464 ms per step, profiles/r04_option_sweeps.txt)
+            args.window = 2
         note(f"sections {bounds} dealt as {owner}: " + ", ".join(f"rank {r} {owned[r] or 'IDLE'} ({load[r]} bases)" for r in range(world)))
     ctxs = []
     score0 = 0

@@ -11,7 +11,9 @@ import torch.distributed as dist
 def gpu_realign_section(rows, bandwidth, device, max_rounds=-1):
     """Default worker: the HIP path through the C ABI.  Returns (rows_out, score_lines)."""
     from .realigner import PWReAligner
-    g = PWReAligner(rows, bandwidth=bandwidth, device=device)
+    # (window 2: inside a Window.py section every row overlaps every other, a third speculative job per batch commits next to never and
+    # takes SIMDs from the sections running beside this one: six sections on one GPU 425 against 464 ms per bench step, DESIGN.md 7)
+    g = PWReAligner(rows, bandwidth=bandwidth, device=device, window=2)
     try:
         g.trim_ends()
         best = g.total_score()
