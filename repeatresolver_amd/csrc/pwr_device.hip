@@ -2866,10 +2866,20 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
         int ylow = max(-1, wx - H) + 1;
         if (ylow > W - 1) ylow = W - 1;
         unsigned long long key = ~0ull;
-        for (int yy = max(ylow, a) + lane; yy < a + Bx; yy += 64) {
-            const unsigned v = lastM[(yy - lo) % RS];
-            const unsigned long long k2 = ((unsigned long long)v << 32) | (unsigned)(~(unsigned)yy);
-            key = k2 < key ? k2 : key;
+        {
+            // (every chunk waits for this one: the scores are fetched in one go -- a loop that loads, compares and loads again pays a
+            // memory round trip per 64 columns, 4 us of the launch's 24 at a bandwidth of 1000)
+            constexpr int EN = (PWR_MAX_BANDWIDTH + 63) / 64;
+            const int y0_ = max(ylow, a) + lane;
+            unsigned ev[EN];
+#pragma unroll
+            for (int i = 0; i < EN; ++i) { const int yy = y0_ + 64 * i; ev[i] = yy < a + Bx ? lastM[(yy - lo) % RS] : 0xffffffffu; }
+#pragma unroll
+            for (int i = 0; i < EN; ++i) {
+                const int yy = y0_ + 64 * i;
+                const unsigned long long k2 = yy < a + Bx ? (((unsigned long long)ev[i] << 32) | (unsigned)(~(unsigned)yy)) : ~0ull;
+                key = k2 < key ? k2 : key;
+            }
         }
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long other = __shfl_xor(key, o);
