@@ -187,6 +187,7 @@ struct JobBufs {
     int seg_balance;               // 1: the own parts are cut so that all segments of a job run about the same number of rows, warm-up included
     int plan_ahead;                // 1: the rows of a batch are picked by the batch before it: rows that commute with every row before them first
     int hard_rows, hard_up, hard_down;  // a row whose check fails warms up over hard_up more columns from then on, hard_down fewer after every commit (1; 2 = only counted)
+    int plan_len;                       // > 0: a row is picked ahead only if it is at most this many percent longer than the batch's first row (0: any length)
     int plan_gate_rel;                  // 1: rows jump only while 64 commits' worth of events stay below half the gap they keep (0: test hook)
     int spec_inorder;                   // with plan_ahead: at most this many speculative rows in order per batch, beside the rows picked ahead
     int fail_stops;                     // 1: a job that failed its segment check ends its batch (test hook; 0: later rows that commute with it may still commit)
@@ -3776,8 +3777,10 @@ __global__ __launch_bounds__(COMMIT_NT) void k_commit_finish(DState st, JobBufs 
             int n = 0;
             s_sel[n] = 0; s_gp[n] = 0x7fffffff; ++n;
             unsigned long long taken = 1ull;
+            const int lcap = jb.plan_len > 0 ? max(0, s_pL[0]) + (int)((long long)max(0, s_pL[0]) * jb.plan_len / 100) + 64 : 0x7fffffff;
             for (unsigned long long q = s_okm & ~1ull; q && n < window; q &= q - 1) {
                 const int off = __builtin_ctzll(q);
+                if (s_pL[off] > lcap) continue;                                    // (test hook: a row picked ahead no longer than this)
                 s_sel[n] = off; s_gp[n] = s_pgap[off]; ++n; taken |= 1ull << off;
             }
             const int l0 = max(0, s_pL[0]);
@@ -3982,7 +3985,7 @@ struct pwr_ctx {
     int seg_max = 64;                     // ... at most this many per DP (<= SEG_MAX)
     int seg_budget = 0;                   // > 0: this many for all the jobs of a batch together, dealt by length (measured slower; 0: seg_rows rows each)
     int seg_minrows = 64;                 // ... none with fewer own rows than this
-    int spec_inorder = 64, plan_gate_rel = 1;
+    int spec_inorder = 64, plan_gate_rel = 1, plan_len = 0;
     int fail_stops = 0, hard_rows = 1, hard_up_pm = 300, hard_down_pm = 0;   // (per mille of the bandwidth)
     int plan_slack = PLAN_SLACK, plan_evrate_x100 = (int)(PLAN_EVRATE_MAX * 100.0f);   // test hooks: the gap a row must keep to be picked ahead, the event rate above which none is
     int plan_ahead = 1;                   // the speculative rows of a batch: rows among the next 64 whose interval is disjoint from every uncommitted row before them first (0: the next rows in order)
@@ -4214,7 +4217,7 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     jb.smax = std::max(1, std::min(c->seg_max, SEG_MAX));
     jb.seg_align = c->seg_align;
     jb.seg_budget = c->seg_budget; jb.seg_minrows = c->seg_minrows; jb.seg_balance = c->seg_balance;
-    jb.spec_inorder = c->spec_inorder; jb.plan_gate_rel = c->plan_gate_rel;
+    jb.spec_inorder = c->spec_inorder; jb.plan_gate_rel = c->plan_gate_rel; jb.plan_len = c->plan_len;
     jb.fail_stops = c->fail_stops; jb.hard_rows = c->hard_rows; jb.hard_up = std::max(1, (int)((long long)c->B * c->hard_up_pm / 1000)); jb.hard_down = (int)((long long)c->B * c->hard_down_pm / 1000);
     jb.plan_ahead = c->plan_ahead; jb.plan_slack = c->plan_slack; jb.plan_evrate_x100 = c->plan_evrate_x100;
     jb.rowids = c->d_rowids;
@@ -5057,6 +5060,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "hard_rows")) { if (c->on_device || value < 0 || value > 2) return PWR_ERR_ARG; c->hard_rows = (int)value; return PWR_OK; }
     if (!strcmp(key, "hard_up_pm")) { if (c->on_device || value < 1 || value > 100000) return PWR_ERR_ARG; c->hard_up_pm = (int)value; return PWR_OK; }
     if (!strcmp(key, "hard_down_pm")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->hard_down_pm = (int)value; return PWR_OK; }
+    if (!strcmp(key, "plan_len")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->plan_len = (int)value; c->jb.plan_len = (int)value; return PWR_OK; }
     if (!strcmp(key, "plan_gate_rel")) { if (value < 0 || value > 1) return PWR_ERR_ARG; c->plan_gate_rel = (int)value; c->jb.plan_gate_rel = (int)value; return PWR_OK; }
     if (!strcmp(key, "spec_inorder")) { if (value < 0 || value > 64) return PWR_ERR_ARG; c->spec_inorder = (int)value; c->jb.spec_inorder = (int)value; return PWR_OK; }
     if (!strcmp(key, "fail_stops")) { if (value < 0 || value > 1) return PWR_ERR_ARG; c->fail_stops = (int)value; c->jb.fail_stops = (int)value; return PWR_OK; }
@@ -5098,6 +5102,7 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "fail_stops")) *value = c->fail_stops;
     else if (!strcmp(key, "spec_inorder")) *value = c->spec_inorder;
     else if (!strcmp(key, "plan_gate_rel")) *value = c->plan_gate_rel;
+    else if (!strcmp(key, "plan_len")) *value = c->plan_len;
     else if (!strcmp(key, "hard_rows")) *value = c->hard_rows;
     else if (!strcmp(key, "hard_up_pm")) *value = c->hard_up_pm;
     else if (!strcmp(key, "hard_down_pm")) *value = c->hard_down_pm;
