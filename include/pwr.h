@@ -160,6 +160,9 @@ void pwr_snapshot_free(pwr_snapshot *snap);
  *               are a property of the row (a row that failed once fails again in 46 % of its fills, any row in 8 %: DESIGN.md
  *               3.2), so the rows that need a long warm-up get one and the steered length of all others comes down; 0: one
  *               length for all (round 3); 2: marked and counted only (read-only "hard_marked", "hard_fills", "hard_refail")
+ *   "check_in_trace"
+ *               1 (default): the work-groups that check the segments' starts ride in the traceback kernel's launch (k_trace_blk) instead of
+ *               a launch of their own between fill and traceback; 0: their own launch
  *   "fail_stops"
  *               0 (default): a row whose segment check failed waits for its repeat like a stale row -- later rows of the batch whose
  *               band intervals are disjoint from its own may commit ahead of it; 1: its batch ends with it (rounds 3's rule)

@@ -202,6 +202,8 @@ struct JobBufs {
     int force64;                   // test hook: every job takes the 64-bit fill
     int evcap;                     // commits with more structural events than this renumber by a pass over the width (test hook; <= EVCAP)
     int gate_v2;                   // k_fill_v2 launched behind k_fill_v3: it runs only while Hdr::fallback > 0
+    int *chkdone;                  // [njobs] boundaries of the job's fill that k_seg_check has been through (reset by the gather)
+    int check_in_trace, trace_ny;  // the check's work-groups ride in k_trace_blk's launch, behind its trace_ny rows of work-groups (one launch less per batch)
     int trace_blk;                 // this batch's traceback is k_trace_blk's (its chunk words carry the 'up' moves of every 64 rows)
     int v2_follows, f64_follows;   // this batch's launches include the stand-in k_fill_v2 / the 64-bit k_fill64 (the host adds them when the
                                    // header it last saw says they are wanted; a job that wanted one in a batch without it is repeated)
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(GATHER_NT) void k_gather_a(DState st, JobBufs jb, c
     if (g == 0) {
         // what the commit of this batch will note about the job (k_commit_scan) starts from nothing
         const int nj = (int)gridDim.x;
-        if (tid == 0) { CommitJob z; z.nchg = z.nev = z.ndel = 0; z.first = 0x7fffffff; z.u0 = z.u1 = 0; z.scanned = 0; z.pad = 0; jb.cjob[job] = z; }
+        if (tid == 0) { CommitJob z; z.nchg = z.nev = z.ndel = 0; z.first = 0x7fffffff; z.u0 = z.u1 = 0; z.scanned = 0; z.pad = 0; jb.cjob[job] = z; jb.chkdone[job] = 0; }
         for (int j = tid; j < nj; j += GATHER_NT) { jb.pair_cf[(size_t)job * nj + j] = 0; jb.pair_left[(size_t)job * nj + j] = 0; }
     }
     if (kk < 0) { if (tid == 0 && g == 0) m->active = 0; return; }
@@ -2073,12 +2075,19 @@ __global__ __launch_bounds__(WG1 ? NW * 64 : 128) void k_fill_v3(DState st, JobB
 // induction the scores segment s - 1 ends on are themselves parallel to the true ones.)  One work-group per (job, s); the
 // entries are consumed (set to "not written"), so a store that went missing can never pass for a match.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_seg_check(DState st, JobBufs jb)
+// (does this job's fill have boundaries to check in this batch?  -- one rule for the check and for whoever waits for it)
+__device__ __forceinline__ bool seg_check_applies(const DState &st, const JobBufs &jb, int job, const JobMeta *m)
+{
+    return m->active && m->L > 0 && m->ok && !m->wide && !m->abort && !(st.hdr->fallback > 0 && jb.v2_follows) && !NOT_MINE(jb, job) && m->nseg > 1;
+}
+
+// one work-group of 256 threads per (job, boundary s); `chkdone[job]` counts the boundaries done (for the traceback kernel, which
+// carries these work-groups in its own launch and must know when the verdict is in before it reports an inconsistent record)
+__device__ __forceinline__ void seg_check_body(const DState &st, const JobBufs &jb, const int job, const int s, const int tid)
 {
     __shared__ int s_min[4], s_max[4], s_bad;
-    const int job = blockIdx.x, s = blockIdx.y + 1, tid = threadIdx.x;
     JobMeta *m = &jb.meta[job];
-    if (!m->active || m->L <= 0 || !m->ok || m->wide || m->abort || (st.hdr->fallback > 0 && jb.v2_follows) || NOT_MINE(jb, job)) return;
+    if (!seg_check_applies(st, jb, job, m)) return;
     if (s >= m->nseg) return;
     const SegDesc *sd = jb.seg + (size_t)job * SEG_MAX + s;
     const int xr = sd->xown - 1;                                                   // the row both segments have
@@ -2105,9 +2114,15 @@ __global__ __launch_bounds__(256) void k_seg_check(DState st, JobBufs jb)
     for (int j = tid; j < RS; j += 256) { cw[j] = 0xffffffffu; ct[j] = 0xffffffffu; }
     if (tid == 0) {
         const int lo_ = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3])), hi_ = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-        if (s_bad || (lo_ != INT_MAX && lo_ != hi_)) m->segfail = 1;
+        if (s_bad || (lo_ != INT_MAX && lo_ != hi_)) __hip_atomic_store(&m->segfail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (s == 1) { atomicAdd(&st.hdr->seg_jobs, 1ull); atomicAdd(&st.hdr->segs, (unsigned long long)m->nseg); }
+        __hip_atomic_fetch_add(&jb.chkdone[job], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+__global__ __launch_bounds__(256) void k_seg_check(DState st, JobBufs jb)
+{
+    seg_check_body(st, jb, (int)blockIdx.x, (int)blockIdx.y + 1, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2717,9 +2732,15 @@ __global__ __launch_bounds__(TRW * 64) void k_trace_par(DState st, JobBufs jb)
 __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
 {
     const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    // The check of the segments' starts rides in this launch (`check_in_trace`): its work-groups come behind the traceback's and
+    // run beside them -- a launch less per batch (5.6 us + a kernel boundary).  The traceback therefore starts without the
+    // verdict: a job whose check fails is traced like any other (its record is that of a DP from other starts: well-formed,
+    // only not the true one), nobody uses the result (k_commit_scan looks at the verdict), and the one thing that must not
+    // happen -- an inconsistent record of such a job reported as an error -- waits for the verdict first (below).
+    if (jb.check_in_trace && (int)blockIdx.y >= jb.trace_ny) { seg_check_body(st, jb, job, (int)blockIdx.y - jb.trace_ny + 1, tid); return; }
     JobMeta *m = &jb.meta[job];
     const int L = UNI(m->L);
-    if (!m->active || L <= 0 || !m->ok || m->abort || m->segfail || (m->wide && !jb.f64_follows) || NOT_MINE(jb, job)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
+    if (!m->active || L <= 0 || !m->ok || m->abort || (!jb.check_in_trace && m->segfail) || (m->wide && !jb.f64_follows) || NOT_MINE(jb, job)) return;   // (not filled: stalled, failed its check, or its batch came without k_fill64)
     const int nch = (L + TB_C - 1) / TB_C;
     // the top chunks first: they are the ones everybody else waits for
     const int c = nch - 1 - UNI((int)blockIdx.y * TB_W + (tid >> 6));
@@ -2997,7 +3018,17 @@ __global__ __launch_bounds__(TB_W * 64) void k_trace_blk(DState st, JobBufs jb)
     }
 #endif
     if (err) {
-        if (lane == 0) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+        if (lane == 0) {
+            bool failed = false;
+            if (jb.check_in_trace && seg_check_applies(st, jb, job, m)) {
+                // the record of a job whose check failed may be anything: wait for the verdict (its work-groups are in this launch,
+                // a few microseconds of work each; bounded all the same)
+                const int want = m->nseg - 1;
+                for (unsigned spin = 0; spin < (1u << 22) && __hip_atomic_load(&jb.chkdone[job], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin) __builtin_amdgcn_s_sleep(8);
+                failed = __hip_atomic_load(&m->segfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            }
+            if (!failed) { m->ok = 0; atomicCAS(&st.hdr->status, 0, PWR_ERR_INTERNAL); }
+        }
         return;
     }
     if (c == 0) {
@@ -3986,6 +4017,7 @@ struct pwr_ctx {
     int seg_budget = 0;                   // > 0: this many for all the jobs of a batch together, dealt by length (measured slower; 0: seg_rows rows each)
     int seg_minrows = 64;                 // ... none with fewer own rows than this
     int spec_inorder = 64, plan_gate_rel = 1, plan_len = 0;
+    int check_in_trace = 1;               // the work-groups of k_seg_check ride in k_trace_blk's launch (0: a launch of their own, as up to round 4's first half)
     int fail_stops = 0, hard_rows = 1, hard_up_pm = 300, hard_down_pm = 0;   // (per mille of the bandwidth)
     int plan_slack = PLAN_SLACK, plan_evrate_x100 = (int)(PLAN_EVRATE_MAX * 100.0f);   // test hooks: the gap a row must keep to be picked ahead, the event rate above which none is
     int plan_ahead = 1;                   // the speculative rows of a batch: rows among the next 64 whose interval is disjoint from every uncommitted row before them first (0: the next rows in order)
@@ -4256,6 +4288,8 @@ static int alloc_jobs(pwr_ctx *c, int njobs)
     if ((rc = dmalloc(c, &jb.sev, 1))) return rc;
     if ((rc = dmalloc(c, &jb.freed, EVCAP))) return rc;
     if ((rc = dmalloc(c, &jb.ticket, 4))) return rc;
+    if ((rc = dmalloc(c, &jb.chkdone, (size_t)njobs))) return rc;
+    if (hipMemsetAsync(jb.chkdone, 0, sizeof(int) * (size_t)njobs, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
     if (hipMemsetAsync(jb.cjob, 0, sizeof(CommitJob) * njobs, c->stream) != hipSuccess || hipMemsetAsync(jb.pair_cf, 0, sizeof(int) * (size_t)njobs * njobs, c->stream) != hipSuccess ||
         hipMemsetAsync(jb.pair_left, 0, sizeof(int) * (size_t)njobs * njobs, c->stream) != hipSuccess || hipMemsetAsync(jb.plan, 0, sizeof(BatchPlan), c->stream) != hipSuccess ||
         hipMemsetAsync(jb.sev, 0, sizeof(CommitEv), c->stream) != hipSuccess || hipMemsetAsync(jb.ticket, 0, 16, c->stream) != hipSuccess) return PWR_ERR_DEVICE;
@@ -4269,7 +4303,7 @@ static void free_jobs(pwr_ctx *c)
     JobBufs &jb = c->jb;
     dfree(c, jb.meta); dfree(c, jb.way); dfree(c, jb.g64); dfree(c, jb.gpart); dfree(c, jb.rec2); dfree(c, jb.mark); dfree(c, jb.mark2);
     dfree(c, jb.dirs); dfree(c, jb.newcol); dfree(c, jb.aux); dfree(c, jb.desc); dfree(c, jb.lastM); dfree(c, jb.gmb); dfree(c, jb.seg); dfree(c, jb.chk); dfree(c, jb.gtr); dfree(c, jb.diag); dfree(c, c->d_jobrows);
-    dfree(c, jb.cjob); dfree(c, jb.chg); dfree(c, jb.evkey); dfree(c, jb.evdl); dfree(c, jb.insidx); dfree(c, jb.pair_cf); dfree(c, jb.pair_left); dfree(c, jb.plan); dfree(c, jb.sev); dfree(c, jb.freed); dfree(c, jb.ticket);
+    dfree(c, jb.cjob); dfree(c, jb.chg); dfree(c, jb.evkey); dfree(c, jb.evdl); dfree(c, jb.insidx); dfree(c, jb.pair_cf); dfree(c, jb.pair_left); dfree(c, jb.plan); dfree(c, jb.sev); dfree(c, jb.freed); dfree(c, jb.ticket); dfree(c, jb.chkdone);
     jb = JobBufs{};
     c->d_jobrows = nullptr;
     c->njobs = 0;
@@ -4550,7 +4584,7 @@ static int launch_fill(pwr_ctx *c, int njobs)
         else if (c->B <= 1024 && c->wave_cols != 4) hipLaunchKernelGGL((k_fill_v3<9, 2, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL((k_fill_v3<9, 4, false>), grid, dim3(128), 0, c->stream, c->st, c->jb);
         c->jb.stall_test = 0;
-        if (c->jb.smax > 1 && c->jb.seg_rows > 0)
+        if (c->jb.smax > 1 && c->jb.seg_rows > 0 && !c->jb.check_in_trace)
             hipLaunchKernelGGL(k_seg_check, dim3(njobs, c->jb.smax - 1), dim3(256), 0, c->stream, c->st, c->jb);
     }
     // k_fill_v2: the fill of its own right (option fill = 3), or the stand-in behind k_fill_v3 that only runs while
@@ -4629,13 +4663,16 @@ static int enqueue_front(pwr_ctx *c)
     c->jb.f64_follows = (c->seen_need64 > 0 || c->force64) ? 1 : 0;
     hipLaunchKernelGGL(k_gather_a, dim3(n, GATHER_G), dim3(GATHER_NT), 0, c->stream, c->st, c->jb, c->d_rowids);
     hipLaunchKernelGGL(k_gather_c, dim3(n, GATHER_G + 1), dim3(GATHER_NT), 0, c->stream, c->st, c->jb);
+    // (the check of the segments' starts rides in k_trace_blk's launch when that is the traceback of this batch)
+    c->jb.trace_ny = (c->jb.Lmax / TB_C + TB_W) / TB_W;
+    c->jb.check_in_trace = (c->check_in_trace && c->fill_mode == 4 && c->par_trace == 2 && c->st.colcap < TB_MAXCOL && c->jb.smax > 1 && c->jb.seg_rows > 0) ? 1 : 0;
     if ((rc = launch_fill(c, n))) return rc;
     if (c->jb.f64_follows) hipLaunchKernelGGL(k_fill64, dim3(n), dim3(F64_NT), 0, c->stream, c->st, c->jb);   // jobs the gather flagged wide
     if (c->par_trace) {
         if (++c->trace_epoch >= (1u << 14)) { HIPC(hipMemsetAsync(c->jb.gtr, 0, (size_t)c->njobs * c->jb.trk * 8, c->stream)); c->trace_epoch = 1; }
         c->jb.trace_tag = c->trace_epoch;
         c->jb.trace_blk = (c->par_trace == 2 && c->st.colcap < TB_MAXCOL) ? 1 : 0;
-        if (c->jb.trace_blk) hipLaunchKernelGGL(k_trace_blk, dim3(n, (c->jb.Lmax / TB_C + TB_W) / TB_W), dim3(TB_W * 64), 0, c->stream, c->st, c->jb);
+        if (c->jb.trace_blk) hipLaunchKernelGGL(k_trace_blk, dim3(n, c->jb.trace_ny + (c->jb.check_in_trace ? c->jb.smax - 1 : 0)), dim3(TB_W * 64), 0, c->stream, c->st, c->jb);
         else hipLaunchKernelGGL(k_trace_par, dim3(n, TRK / TRW), dim3(TRW * 64), 0, c->stream, c->st, c->jb);
     }
     else { c->jb.trace_blk = 0; hipLaunchKernelGGL(k_trace_wp, dim3(n), dim3(64), 0, c->stream, c->st, c->jb); }
@@ -5060,6 +5097,7 @@ extern "C" int pwr_set_option(pwr_ctx *c, const char *key, long value)
     if (!strcmp(key, "hard_rows")) { if (c->on_device || value < 0 || value > 2) return PWR_ERR_ARG; c->hard_rows = (int)value; return PWR_OK; }
     if (!strcmp(key, "hard_up_pm")) { if (c->on_device || value < 1 || value > 100000) return PWR_ERR_ARG; c->hard_up_pm = (int)value; return PWR_OK; }
     if (!strcmp(key, "hard_down_pm")) { if (c->on_device || value < 0 || value > 100000) return PWR_ERR_ARG; c->hard_down_pm = (int)value; return PWR_OK; }
+    if (!strcmp(key, "check_in_trace")) { if (value < 0 || value > 1) return PWR_ERR_ARG; c->check_in_trace = (int)value; return PWR_OK; }
     if (!strcmp(key, "plan_len")) { if (value < 0 || value > 100000) return PWR_ERR_ARG; c->plan_len = (int)value; c->jb.plan_len = (int)value; return PWR_OK; }
     if (!strcmp(key, "plan_gate_rel")) { if (value < 0 || value > 1) return PWR_ERR_ARG; c->plan_gate_rel = (int)value; c->jb.plan_gate_rel = (int)value; return PWR_OK; }
     if (!strcmp(key, "spec_inorder")) { if (value < 0 || value > 64) return PWR_ERR_ARG; c->spec_inorder = (int)value; c->jb.spec_inorder = (int)value; return PWR_OK; }
@@ -5103,6 +5141,7 @@ extern "C" int pwr_get_option(pwr_ctx *c, const char *key, long *value)
     else if (!strcmp(key, "spec_inorder")) *value = c->spec_inorder;
     else if (!strcmp(key, "plan_gate_rel")) *value = c->plan_gate_rel;
     else if (!strcmp(key, "plan_len")) *value = c->plan_len;
+    else if (!strcmp(key, "check_in_trace")) *value = c->check_in_trace;
     else if (!strcmp(key, "hard_rows")) *value = c->hard_rows;
     else if (!strcmp(key, "hard_up_pm")) *value = c->hard_up_pm;
     else if (!strcmp(key, "hard_down_pm")) *value = c->hard_down_pm;

@@ -115,8 +115,8 @@ def test_failed_segment_check_repeats_the_row_in_one_piece(oracle):
     from repeatresolver_amd.realigner import PWReAligner
     for name, bw in (("toy_b_b1000", 1000), ("deep_b200", 200)):
         rows = split_rows(golden_input(name))
-        for window in (1, 4):
-            g = PWReAligner(rows, bandwidth=bw, window=window, seg_rows=128, seg_max=64, warm_pct=20)
+        for window, fold in ((1, 1), (4, 1), (4, 0)):            # (fold: the check's work-groups ride in the traceback's launch, or have their own)
+            g = PWReAligner(rows, bandwidth=bw, window=window, seg_rows=128, seg_max=64, warm_pct=20, check_in_trace=fold)
             g.trim_ends()
             h = oracle.create(rows, bw)
             oracle.lib.pwo_trim(h)
