@@ -164,8 +164,9 @@ void pwr_snapshot_free(pwr_snapshot *snap);
  *               1 (default): the work-groups that check the segments' starts ride in the traceback kernel's launch (k_trace_blk) instead of
  *               a launch of their own between fill and traceback; 0: their own launch
  *   "fail_stops"
- *               0 (default): a row whose segment check failed waits for its repeat like a stale row -- later rows of the batch whose
- *               band intervals are disjoint from its own may commit ahead of it; 1: its batch ends with it (rounds 3's rule)
+ *               1 (default): a job whose segment check failed ends its batch (round 3's rule); 0 (experimental): it waits for its
+ *               repeat like a stale row -- later rows of the batch whose band intervals are disjoint from its own commit ahead of
+ *               it; 0.7 % faster, but one case of the randomised sweep fails with it: not for production
  *   "seg_balance"
  *               1: the own parts of a job's segments are cut so that every segment runs about the same number of rows, its warm-up
  *               included (the first has none; a warm-up of so many columns is more rows where the bases sit closer); default 0 =

@@ -53,7 +53,7 @@ while time.time() < t_end:
                 onewg=int(rng.choice([0, 0, 1])), seg_align=int(rng.choice([16, 32, 64])), slack=int(rng.choice([0, 8192])),
                 src_start=int(rng.choice([0, 1, 1])), warm_adapt=int(rng.choice([0, 1, 1])), warm_min_pct=int(rng.choice([10, 50, 100])),
                 seg_budget=int(rng.choice([0, 0, 12, 200])), seg_minrows=int(rng.choice([16, 64])), seg_balance=int(rng.choice([0, 1, 1])), plan_ahead=int(rng.choice([0, 1, 1])), plan_slack=int(rng.choice([1024, 1024, 64])), evcap=int(rng.choice([1024, 1024, 1024, 0, 3])),
-                hard_rows=int(rng.choice([0, 1, 1, 2])), hard_up_pm=int(rng.choice([100, 300, 1000])), hard_down_pm=int(rng.choice([0, 0, 50])), fail_stops=int(rng.choice([0, 0, 1])),
+                hard_rows=int(rng.choice([0, 1, 1, 2])), hard_up_pm=int(rng.choice([100, 300, 1000])), hard_down_pm=int(rng.choice([0, 0, 50])), fail_stops=int(rng.choice([1, 1, 1, 0])),
                 spec_inorder=int(rng.choice([64, 64, 0, 1])), wave_cols=int(rng.choice([0, 0, 4])))
     if opts["waves"] != 9: opts["wave_cols"] = 0
     # (rows without bases: the k loop runs over the others)

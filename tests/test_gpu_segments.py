@@ -298,8 +298,8 @@ def test_rows_picked_ahead_commute_and_commit(oracle):
 
 def test_rows_commit_past_a_row_whose_check_failed(oracle):
     """A job whose segment check failed is repeated in the next batch; until then it is an uncommitted row like a stale one,
-    and a later row of the batch that commutes with it may commit ahead of it (round 4; `fail_stops` 1: the batch ends at
-    the failed job, as before).  Far too short a warm-up makes many checks fail: same MSA as the reference's after every
+    and a later row of the batch that commutes with it may commit ahead of it (`fail_stops` 0, experimental; 1, the default: the
+    batch ends at the failed job).  Far too short a warm-up makes many checks fail: same MSA as the reference's after every
     round either way, fewer batches with the rows that go past."""
     from repeatresolver_amd import datagen as dg
     from repeatresolver_amd.realigner import PWReAligner
