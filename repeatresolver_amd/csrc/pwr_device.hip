@@ -4756,7 +4756,11 @@ static int realign_positions(pwr_ctx *c, int k0, int n, bool resume = false)   /
             seqs[slot] = c->host_seq;
             ++issued;
         }
-        if (looked == issued) { (void)hipStreamSynchronize(c->stream); return PWR_ERR_INTERNAL; }   // rows left although every batch commits one: cannot happen
+        if (looked == issued) {                                                // rows left although every batch commits one: cannot happen
+            (void)hipStreamSynchronize(c->stream);
+            fprintf(stderr, "pwr: %lld batches issued for %d rows and rows are left (host guard, not the traceback's error)\n", issued, n);
+            return PWR_ERR_INTERNAL;
+        }
         const int slot = (int)(looked % PWR_INFLIGHT);
         {
             // wait for that batch's header: poll the sequence number (pinned memory), look at the stream now and then in case
